@@ -1,0 +1,169 @@
+/*
+ * raymarching_amd.h - C ABI of the MI355X raymarch backend.
+ *
+ * This is the whole host<->device boundary of the per-pixel hot path.  It takes
+ * the place of the reference's CUDA driver glue (Include/cuda_rays.cuh:14-46,
+ * Include/cuda_defines.cuh, Source/cuda_rays.cu) behind the reference's abstract
+ * backend interface `null::raymarching` (Include/rays.h:15-69).  Each entry
+ * point cites the reference interface it replaces; paths are relative to the
+ * reference checkout.  Plain pointers and sizes only.
+ *
+ * Conventions (Source/cuda_rays.cu:3-5): every call returns 0 on success.  A
+ * positive value is a hipError_t, a negative value one of enum rm_status.
+ * Unlike the reference, an error is never latched and silently carried on.
+ * All calls are synchronous on the context's stream unless stated otherwise.
+ * A context is not thread-safe; use one per host thread / per GPU.
+ *
+ * Call protocol (Source/main.cpp:67-138,269-270,292-293):
+ *   rm_create -> [rm_set_output] -> rm_set_primitives|rm_set_nodes -> rm_set_info
+ *   -> per frame { rm_set_info, rm_process } -> rm_read_pixels -> rm_destroy
+ */
+#ifndef RAYMARCHING_AMD_H
+#define RAYMARCHING_AMD_H
+
+#include "rm_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rm_ctx rm_ctx;
+
+enum rm_status {
+    RM_OK              =  0,
+    RM_ERR_INVALID_ARG = -1,  /* null pointer, zero size, bad enum value            */
+    RM_ERR_BAD_SCENE   = -2,  /* unknown/nenio node reachable, link out of range     */
+    RM_ERR_UNSUPPORTED = -3,  /* record not representable in the given layout        */
+    RM_ERR_IO          = -4,  /* file could not be read / written / wrong size       */
+    RM_ERR_TOO_LARGE   = -5,  /* scene exceeds RM_MAX_NODES or the LDS budget        */
+    RM_ERR_NOT_READY   = -6,  /* rm_process before primitives and info were set      */
+    RM_ERR_NO_KERNEL   = -7   /* the HIP code object for gfx950 could not be loaded  */
+};
+
+#define RM_MAX_NODES 2048     /* reference: 256 (Source/cuda_kernels.cu:607) */
+
+/* ---- scene tables ------------------------------------------------------- */
+
+/* Decode `n` 48-byte `primitives::bazo` records (Include/types.h:56-61) given
+ * in `layout` (enum rm_bazo_layout) into canonical nodes.  The dist/norm
+ * function-pointer fields are ignored, as kernel_SetPrimitives
+ * (Source/cuda_kernels.cu:721-728) would overwrite them. */
+int rm_decode_bazo(const void* records, size_t n, int layout, rm_node* out);
+
+/* Read a `.sce` scene table (Scenes/NAME.sce; the file named by `--input`,
+ * Source/main.cpp:29-31).  Writes at most `cap` nodes; *n receives the number
+ * of records in the file. */
+int rm_load_sce(const char* path, rm_node* out, size_t cap, size_t* n);
+
+/* Write canonical nodes as a `.sce` table (4-byte counters). */
+int rm_save_sce(const char* path, const rm_node* nodes, size_t n);
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Init (Include/rays.h:29; Source/cuda_rays.cu:17-199): bind `device`, create
+ * the stream and timing events, allocate the width x height RGBA8 framebuffer.
+ * No ray buffer is allocated: ray generation is fused into the march kernel. */
+int rm_create(int device, size_t width, size_t height, rm_ctx** out);
+
+/* UnsetTexture + Quit (Include/rays.h:41,47; Source/cuda_rays.cu:218-227,256-264). */
+int rm_destroy(rm_ctx* ctx);
+
+/* Launch on a caller-owned hipStream_t instead of the context's own stream
+ * (replaces the fixed `_default_stream`, Include/cuda_defines.cuh:9-10).
+ * NULL selects the null stream. */
+int rm_set_stream(rm_ctx* ctx, void* hip_stream);
+
+/* SetTexture (Include/rays.h:46; Source/cuda_rays.cu:241-254): render into a
+ * caller-owned DEVICE buffer of RGBA8 rows `pitch_bytes` apart instead of the
+ * context's framebuffer.  Row 0 is the top row and pixel x sits at byte x*4,
+ * as surf2Dwrite does at Source/cuda_kernels.cu:717.  NULL restores the
+ * context's own framebuffer. */
+int rm_set_output(rm_ctx* ctx, void* device_rgba, size_t pitch_bytes);
+
+/* AddPrimitive... + SetPrimitives (Include/rays.h:49,57-64; Source/cuda_rays.cu:266-287):
+ * copy the host table, validate it, flatten it into the device scene program
+ * and upload.  kernel_SetPrimitives' function-pointer binding has no
+ * counterpart: node types are resolved while flattening. */
+int rm_set_primitives(rm_ctx* ctx, const void* bazo_records, size_t n, int layout);
+int rm_set_nodes(rm_ctx* ctx, const rm_node* nodes, size_t n);
+
+/* SetInfo (Include/rays.h:44; Source/cuda_rays.cu:230-239).  The struct is
+ * copied before the call returns.  kernel_SetRays (Source/cuda_kernels.cu:730-762)
+ * is not launched: rm_process derives each pixel's ray from this block. */
+int rm_set_info(rm_ctx* ctx, const rm_rays_info* info);
+
+/* Multi-GPU row bands (no counterpart: the reference is single-device,
+ * Source/cuda_rays.cu:20-21).  The image is cut into bands of `band_rows` rows
+ * (a multiple of 16); this context renders bands b with b % nranks == rank,
+ * packed top to bottom into its output buffer.  rm_local_rows reports how many
+ * rows that is.  band_rows = 0 restores whole-frame rendering. */
+int rm_set_bands(rm_ctx* ctx, size_t band_rows, int rank, int nranks);
+int rm_local_rows(rm_ctx* ctx, size_t* rows);
+
+/* Optional explicit hit mask: one byte per
+ * pixel, 1 where the pixel was shaded.  enable != 0 allocates it. */
+int rm_enable_hit_mask(rm_ctx* ctx, int enable);
+
+/* Process (Include/rays.h:35; Source/cuda_rays.cu:201-216): render one frame
+ * and wait for it.  *elapsed_ms (optional) receives the kernel time between two
+ * stream events as a float; the reference returns it truncated to whole ms. */
+int rm_process(rm_ctx* ctx, float* elapsed_ms);
+
+/* Same launch without events and without waiting: for back-to-back frames
+ * timed by the caller on the context's stream. */
+int rm_process_async(rm_ctx* ctx);
+int rm_synchronize(rm_ctx* ctx);
+
+/* Copy the local rows of the framebuffer (or hit mask) to host memory. */
+int rm_read_pixels(rm_ctx* ctx, void* host_rgba, size_t pitch_bytes);
+int rm_read_hit_mask(rm_ctx* ctx, void* host_mask, size_t pitch_bytes);
+
+/* Device address and pitch of the buffer rm_process writes. */
+int rm_device_framebuffer(rm_ctx* ctx, void** device_rgba, size_t* pitch_bytes);
+
+/* ---- introspection ------------------------------------------------------ */
+
+typedef struct rm_scene_stats {
+    uint32_t nodes;            /* records in the node table                    */
+    uint32_t reachable;        /* nodes reachable from node 0                  */
+    uint32_t program_slots;    /* 32-byte slots of the wave-uniform program    */
+    uint32_t value_slots;      /* per-lane LDS dwords used by the program      */
+    uint32_t tree_depth;       /* longest root-to-leaf path                    */
+    uint32_t lds_bytes;        /* dynamic LDS per 256-thread workgroup         */
+    uint32_t kernel_vgprs;     /* register footprint reported by the runtime   */
+    uint32_t kernel_scratch;   /* private (scratch) bytes per lane             */
+} rm_scene_stats;
+int rm_get_scene_stats(rm_ctx* ctx, rm_scene_stats* out);
+
+/* Host-only: validate and flatten a node table without touching a device.
+ * stats (optional) receives the host-side fields; listing (optional) receives a
+ * NUL-terminated text listing of the distance program, truncated to cap. */
+int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char* listing, size_t cap);
+
+/* Tuning: how many of a wavefront's lanes must be waiting for a surface normal
+ * before the wave leaves the march loop to compute them (1..64).  Results do
+ * not depend on it. */
+int rm_set_norm_batch(rm_ctx* ctx, int lanes);
+
+/* Which evaluator computes root distances: 0 = wave-uniform scene program
+ * (default), 1 = per-lane tree walker (diagnostic; identical results). */
+int rm_set_evaluator(rm_ctx* ctx, int which);
+
+const char* rm_status_string(int status);
+
+/* ---- node-level evaluation on the device (known-answer tests) ----------- */
+
+/* Evaluate DIST/NORM of node `idx` of the context's scene at `count` points
+ * (host arrays of xyz triples) with the device evaluators.  which: 0 = program
+ * (idx must be 0), 1 = tree walker.  norm_out may be NULL. */
+int rm_eval_points(rm_ctx* ctx, int which, size_t idx, const float* xyz, size_t count,
+                   float* dist_out, float* norm_out);
+
+/* kernel_SetRays known-answer hook: the rays the march kernel derives for
+ * `count` pixels (xy pairs), as 6 floats p.xyz d.xyz each. */
+int rm_eval_rays(rm_ctx* ctx, const int32_t* xy, size_t count, float* ray_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYMARCHING_AMD_H */

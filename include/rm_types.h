@@ -97,7 +97,7 @@ enum rm_bazo_layout {
     /* Same field order compiled LLP64 (the reference's own Windows x64
      * target): 4-byte counters. */
     RM_BAZO_LLP64 = 1,
-    /* The on-disk `.sce` record (Scenes/*.sce): payload@0 with 4-byte
+    /* The on-disk `.sce` record (Scenes/NAME.sce): payload@0 with 4-byte
      * counters, dist@24, norm@32, type@40, 4 pad bytes. */
     RM_BAZO_SCE   = 2
 };

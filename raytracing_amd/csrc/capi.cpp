@@ -1,0 +1,391 @@
+// capi.cpp - the C ABI declared in include/raymarching_amd.h: a thin host layer
+// over HIP that takes the place of the reference's CUDA driver glue
+// (Source/cuda_rays.cu).  No CPU rendering path exists here: without a HIP
+// device every call that would render fails with the HIP error.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/raymarching_amd.h"
+#include "kernel_params.h"
+#include "scene_build.h"
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return static_cast<int>(e_); } while (0)
+
+struct rm_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t width = 0, height = 0;
+
+    uint8_t* fb = nullptr;            // own framebuffer, width*4 pitch, `height` rows
+    uint8_t* out = nullptr;           // where rm_process writes (fb or caller's buffer)
+    size_t out_pitch = 0;
+    uint8_t* hit = nullptr;           // optional hit mask, width pitch
+
+    rm::SceneBuild scene;
+    rm::Slot* d_program = nullptr;
+    rm::TreeNode* d_tree = nullptr;
+    uint32_t n_nodes = 0;
+    bool have_scene = false, have_info = false;
+    rm::Camera cam{};
+
+    size_t band_rows = 0; int rank = 0, nranks = 1;
+    size_t local_rows = 0;
+    uint32_t norm_batch = 16, evaluator = 0;
+    size_t lds_bytes = 0;
+    int vgprs = 0, scratch = 0;
+};
+
+namespace {
+
+constexpr size_t kLdsLimit = 160 * 1024 - 1024;   // LDS per CU on gfx950, less a margin
+
+size_t count_local_rows(size_t height, size_t band_rows, int rank, int nranks) {
+    if (!band_rows) return height;
+    size_t rows = 0;
+    for (size_t b = 0, y = 0; y < height; ++b, y += band_rows)
+        if (static_cast<int>(b % static_cast<size_t>(nranks)) == rank)
+            rows += (height - y < band_rows) ? height - y : band_rows;
+    return rows;
+}
+
+void fill_params(const rm_ctx* c, rm::RenderParams& p) {
+    std::memset(&p, 0, sizeof p);
+    p.program = c->d_program;
+    p.tree = c->d_tree;
+    p.n_nodes = c->n_nodes;
+    p.width = static_cast<uint32_t>(c->width);
+    p.height = static_cast<uint32_t>(c->height);
+    p.local_rows = static_cast<uint32_t>(c->local_rows);
+    p.band_rows = static_cast<uint32_t>(c->band_rows);
+    p.rank = static_cast<uint32_t>(c->rank);
+    p.nranks = static_cast<uint32_t>(c->nranks);
+    p.norm_batch = c->norm_batch;
+    p.evaluator = c->evaluator;
+    p.rgba = c->out; p.pitch = c->out_pitch;
+    p.hit = c->hit;  p.hit_pitch = c->width;
+    p.cam = c->cam;
+}
+
+int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
+    rm::SceneBuild built;
+    int rc = rm::build_scene(nodes, n, built);
+    if (rc != RM_OK) return rc;
+    const size_t lds = built.tree.size() * sizeof(rm::TreeNode) +
+                       static_cast<size_t>(built.value_slots) * RM_BLOCK_THREADS * sizeof(float);
+    if (lds > kLdsLimit) return RM_ERR_TOO_LARGE;
+    if (rm::configure_lds(lds) != hipSuccess) return RM_ERR_TOO_LARGE;
+
+    HIP_TRY(hipSetDevice(c->device));
+    rm::Slot* d_prog = nullptr; rm::TreeNode* d_tree = nullptr;
+    HIP_TRY(hipMalloc(&d_prog, built.program.size() * sizeof(rm::Slot)));
+    hipError_t e = hipMalloc(&d_tree, built.tree.size() * sizeof(rm::TreeNode));
+    if (e != hipSuccess) { (void)hipFree(d_prog); return static_cast<int>(e); }
+    e = hipMemcpyAsync(d_prog, built.program.data(), built.program.size() * sizeof(rm::Slot), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_tree, built.tree.data(), built.tree.size() * sizeof(rm::TreeNode), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(d_prog); (void)hipFree(d_tree); return static_cast<int>(e); }
+
+    if (c->d_program) (void)hipFree(c->d_program);
+    if (c->d_tree) (void)hipFree(c->d_tree);
+    c->d_program = d_prog; c->d_tree = d_tree;
+    c->n_nodes = static_cast<uint32_t>(built.tree.size());
+    c->lds_bytes = lds;
+    c->scene = std::move(built);
+    c->have_scene = true;
+    return RM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rm_decode_bazo(const void* records, size_t n, int layout, rm_node* out) {
+    return rm::decode_bazo(records, n, layout, out);
+}
+
+int rm_load_sce(const char* path, rm_node* out, size_t cap, size_t* n) {
+    if (!path || !n) return RM_ERR_INVALID_ARG;
+    std::vector<rm_node> nodes;
+    int rc = rm::load_sce(path, nodes);
+    if (rc != RM_OK) return rc;
+    *n = nodes.size();
+    if (out) std::memcpy(out, nodes.data(), sizeof(rm_node) * (nodes.size() < cap ? nodes.size() : cap));
+    return RM_OK;
+}
+
+int rm_save_sce(const char* path, const rm_node* nodes, size_t n) { return rm::save_sce(path, nodes, n); }
+
+int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
+    if (!out || width == 0 || height == 0 || width > (1u << 20) || height > (1u << 20)) return RM_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    rm_ctx* c = new (std::nothrow) rm_ctx;
+    if (!c) return static_cast<int>(hipErrorOutOfMemory);
+    c->device = device; c->width = width; c->height = height;
+    hipError_t e = hipStreamCreate(&c->own_stream);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc(&c->fb, width * height * 4);
+    if (e == hipSuccess) e = rm::kernel_attributes(&c->vgprs, &c->scratch);
+    if (e != hipSuccess) { rm_destroy(c); return e == hipErrorInvalidDeviceFunction ? RM_ERR_NO_KERNEL : static_cast<int>(e); }
+    c->stream = c->own_stream;
+    c->out = c->fb; c->out_pitch = width * 4;
+    c->local_rows = height;
+    *out = c;
+    return RM_OK;
+}
+
+int rm_destroy(rm_ctx* c) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->d_program) (void)hipFree(c->d_program);
+    if (c->d_tree) (void)hipFree(c->d_tree);
+    if (c->fb) (void)hipFree(c->fb);
+    if (c->hit) (void)hipFree(c->hit);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RM_OK;
+}
+
+int rm_set_stream(rm_ctx* c, void* hip_stream) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    return RM_OK;
+}
+
+int rm_set_output(rm_ctx* c, void* device_rgba, size_t pitch_bytes) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    if (!device_rgba) { c->out = c->fb; c->out_pitch = c->width * 4; return RM_OK; }
+    if (pitch_bytes < c->width * 4 || (pitch_bytes & 3) || (reinterpret_cast<uintptr_t>(device_rgba) & 3))
+        return RM_ERR_INVALID_ARG;
+    c->out = static_cast<uint8_t*>(device_rgba); c->out_pitch = pitch_bytes;
+    return RM_OK;
+}
+
+int rm_set_primitives(rm_ctx* c, const void* bazo_records, size_t n, int layout) {
+    if (!c || !bazo_records || n == 0) return RM_ERR_INVALID_ARG;
+    if (n > RM_MAX_NODES) return RM_ERR_TOO_LARGE;
+    std::vector<rm_node> nodes(n);
+    int rc = rm::decode_bazo(bazo_records, n, layout, nodes.data());
+    if (rc != RM_OK) return rc;
+    return upload_scene(c, nodes.data(), n);
+}
+
+int rm_set_nodes(rm_ctx* c, const rm_node* nodes, size_t n) {
+    if (!c || !nodes || n == 0) return RM_ERR_INVALID_ARG;
+    return upload_scene(c, nodes, n);
+}
+
+int rm_set_info(rm_ctx* c, const rm_rays_info* info) {
+    if (!c || !info) return RM_ERR_INVALID_ARG;
+    rm::Camera& k = c->cam;
+    k.depth = static_cast<float>(info->Depth);           // Source/cuda_kernels.cu:744
+    const rm_point* src[5] = { &info->LightSource, &info->StartPos, &info->StartDir, &info->StartWVec, &info->StartHVec };
+    float* dst[5] = { k.light, k.pos, k.dir, k.wvec, k.hvec };
+    for (int i = 0; i < 5; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+    c->have_info = true;
+    return RM_OK;
+}
+
+int rm_set_bands(rm_ctx* c, size_t band_rows, int rank, int nranks) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    if (band_rows == 0) { c->band_rows = 0; c->rank = 0; c->nranks = 1; c->local_rows = c->height; return RM_OK; }
+    if ((band_rows % 16) || nranks < 1 || rank < 0 || rank >= nranks) return RM_ERR_INVALID_ARG;
+    c->band_rows = band_rows; c->rank = rank; c->nranks = nranks;
+    c->local_rows = count_local_rows(c->height, band_rows, rank, nranks);
+    return RM_OK;
+}
+
+int rm_local_rows(rm_ctx* c, size_t* rows) {
+    if (!c || !rows) return RM_ERR_INVALID_ARG;
+    *rows = c->local_rows;
+    return RM_OK;
+}
+
+int rm_enable_hit_mask(rm_ctx* c, int enable) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (enable && !c->hit) { HIP_TRY(hipMalloc(&c->hit, c->width * c->height)); }
+    if (!enable && c->hit) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->hit); c->hit = nullptr; }
+    return RM_OK;
+}
+
+int rm_process_async(rm_ctx* c) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    if (!c->have_scene || !c->have_info) return RM_ERR_NOT_READY;
+    if (c->local_rows == 0) return RM_OK;
+    // launch-shape checks: everything the kernel indexes must match what was allocated
+    if (!c->out || c->out_pitch < c->width * 4 || !c->d_program || !c->d_tree ||
+        c->n_nodes != c->scene.tree.size() || c->local_rows > c->height) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    rm::RenderParams p;
+    fill_params(c, p);
+    dim3 grid(static_cast<unsigned>((c->width + 15) / 16), static_cast<unsigned>((c->local_rows + 15) / 16));
+    return static_cast<int>(rm::launch_render(p, grid, c->lds_bytes, c->stream));
+}
+
+int rm_synchronize(rm_ctx* c) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_process(rm_ctx* c, float* elapsed_ms) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    int rc = rm_process_async(c);
+    if (rc != RM_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return RM_OK;
+}
+
+int rm_read_pixels(rm_ctx* c, void* host_rgba, size_t pitch_bytes) {
+    if (!c || !host_rgba || pitch_bytes < c->width * 4) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->local_rows == 0) return RM_OK;
+    HIP_TRY(hipMemcpy2DAsync(host_rgba, pitch_bytes, c->out, c->out_pitch, c->width * 4, c->local_rows,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_read_hit_mask(rm_ctx* c, void* host_mask, size_t pitch_bytes) {
+    if (!c || !host_mask || pitch_bytes < c->width) return RM_ERR_INVALID_ARG;
+    if (!c->hit) return RM_ERR_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->local_rows == 0) return RM_OK;
+    HIP_TRY(hipMemcpy2DAsync(host_mask, pitch_bytes, c->hit, c->width, c->width, c->local_rows,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+int rm_device_framebuffer(rm_ctx* c, void** device_rgba, size_t* pitch_bytes) {
+    if (!c || !device_rgba) return RM_ERR_INVALID_ARG;
+    *device_rgba = c->out;
+    if (pitch_bytes) *pitch_bytes = c->out_pitch;
+    return RM_OK;
+}
+
+int rm_get_scene_stats(rm_ctx* c, rm_scene_stats* out) {
+    if (!c || !out) return RM_ERR_INVALID_ARG;
+    if (!c->have_scene) return RM_ERR_NOT_READY;
+    out->nodes = c->n_nodes;
+    out->reachable = c->scene.reachable;
+    out->program_slots = static_cast<uint32_t>(c->scene.program.size());
+    out->value_slots = c->scene.value_slots;
+    out->tree_depth = c->scene.tree_depth;
+    out->lds_bytes = static_cast<uint32_t>(c->lds_bytes);
+    out->kernel_vgprs = static_cast<uint32_t>(c->vgprs);
+    out->kernel_scratch = static_cast<uint32_t>(c->scratch);
+    return RM_OK;
+}
+
+int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char* listing, size_t cap) {
+    rm::SceneBuild built;
+    int rc = rm::build_scene(nodes, n, built);
+    if (rc != RM_OK) return rc;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->nodes = static_cast<uint32_t>(built.tree.size());
+        stats->reachable = built.reachable;
+        stats->program_slots = static_cast<uint32_t>(built.program.size());
+        stats->value_slots = built.value_slots;
+        stats->tree_depth = built.tree_depth;
+        stats->lds_bytes = static_cast<uint32_t>(built.tree.size() * sizeof(rm::TreeNode) +
+                                                 static_cast<size_t>(built.value_slots) * RM_BLOCK_THREADS * sizeof(float));
+    }
+    if (listing && cap) {
+        std::string text = rm::disassemble(built.program);
+        size_t k = text.size() < cap - 1 ? text.size() : cap - 1;
+        std::memcpy(listing, text.data(), k);
+        listing[k] = 0;
+    }
+    return RM_OK;
+}
+
+int rm_set_norm_batch(rm_ctx* c, int lanes) {
+    if (!c || lanes < 1 || lanes > 64) return RM_ERR_INVALID_ARG;
+    c->norm_batch = static_cast<uint32_t>(lanes);
+    return RM_OK;
+}
+
+int rm_set_evaluator(rm_ctx* c, int which) {
+    if (!c || (which != 0 && which != 1)) return RM_ERR_INVALID_ARG;
+    c->evaluator = static_cast<uint32_t>(which);
+    return RM_OK;
+}
+
+const char* rm_status_string(int status) {
+    switch (status) {
+    case RM_OK: return "ok";
+    case RM_ERR_INVALID_ARG: return "invalid argument";
+    case RM_ERR_BAD_SCENE: return "bad scene: nenio/unknown node reachable or child link out of range";
+    case RM_ERR_UNSUPPORTED: return "record not representable in the given bazo layout";
+    case RM_ERR_IO: return "scene file could not be read or written";
+    case RM_ERR_TOO_LARGE: return "scene too large (nodes, tree depth, program slots or LDS)";
+    case RM_ERR_NOT_READY: return "primitives and rays_info must be set first";
+    case RM_ERR_NO_KERNEL: return "no gfx950 code object for this device";
+    default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
+    }
+}
+
+int rm_eval_points(rm_ctx* c, int which, size_t idx, const float* xyz, size_t count, float* dist_out, float* norm_out) {
+    if (!c || !xyz || !dist_out || count == 0 || count > (1u << 24) || (which != 0 && which != 1)) return RM_ERR_INVALID_ARG;
+    if (!c->have_scene) return RM_ERR_NOT_READY;
+    if (idx >= c->n_nodes || (which == 0 && idx != 0)) return RM_ERR_INVALID_ARG;
+    if (!c->scene.seen[idx]) return RM_ERR_INVALID_ARG;   // not reachable from node 0: never flattened
+    HIP_TRY(hipSetDevice(c->device));
+    float *d_xyz = nullptr, *d_dist = nullptr, *d_norm = nullptr;
+    hipError_t e = hipMalloc(&d_xyz, count * 12);
+    if (e == hipSuccess) e = hipMalloc(&d_dist, count * 4);
+    if (e == hipSuccess && norm_out) e = hipMalloc(&d_norm, count * 12);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, xyz, count * 12, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rm::RenderParams p;
+        fill_params(c, p);
+        e = rm::launch_eval_points(p, which, static_cast<uint32_t>(idx), d_xyz, static_cast<uint32_t>(count),
+                                   d_dist, d_norm, c->lds_bytes, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dist_out, d_dist, count * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && norm_out) e = hipMemcpyAsync(norm_out, d_norm, count * 12, hipMemcpyDeviceToHost, c->stream);
+    hipError_t s = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = s;
+    (void)hipFree(d_xyz); (void)hipFree(d_dist); (void)hipFree(d_norm);
+    return static_cast<int>(e);
+}
+
+int rm_eval_rays(rm_ctx* c, const int32_t* xy, size_t count, float* ray_out) {
+    if (!c || !xy || !ray_out || count == 0 || count > (1u << 24)) return RM_ERR_INVALID_ARG;
+    if (!c->have_info) return RM_ERR_NOT_READY;
+    HIP_TRY(hipSetDevice(c->device));
+    int* d_xy = nullptr; float* d_out = nullptr;
+    hipError_t e = hipMalloc(&d_xy, count * 8);
+    if (e == hipSuccess) e = hipMalloc(&d_out, count * 24);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xy, xy, count * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rm::RenderParams p;
+        fill_params(c, p);
+        e = rm::launch_eval_rays(p, d_xy, static_cast<uint32_t>(count), d_out, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ray_out, d_out, count * 24, hipMemcpyDeviceToHost, c->stream);
+    hipError_t s = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = s;
+    (void)hipFree(d_xy); (void)hipFree(d_out);
+    return static_cast<int>(e);
+}
+
+}  // extern "C"

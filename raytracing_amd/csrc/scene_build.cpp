@@ -1,0 +1,449 @@
+// scene_build.cpp - bazo/.sce codecs, scene validation and flattening.
+//
+// Compiled without FMA contraction (-ffp-contract=off): the two scene constants
+// hoisted here (rotacioQ's matrix, Source/cuda_kernels.cu:504-525, and
+// senfina_ripeto's dot(a,a), :578) must round exactly as the per-call
+// computation in the reference does.
+#include "scene_build.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace rm {
+
+// ---------------------------------------------------------------- type tables
+
+int node_arity(uint32_t type) {
+    switch (type) {
+    case RM_TYPE_SFERO: case RM_TYPE_KUBO: case RM_TYPE_CILINDRO: case RM_TYPE_EBENO: return 0;
+    case RM_TYPE_PORTANTA_SFERO: case RM_TYPE_KOMPLEMENTO: case RM_TYPE_MOVO:
+    case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY: case RM_TYPE_ROTACIOZ:
+    case RM_TYPE_ROTACIOQ: case RM_TYPE_SENFINA_RIPETO: return 1;
+    case RM_TYPE_KUNIGAJO_2: case RM_TYPE_KOMUNAJO_2:
+    case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: return 2;
+    case RM_TYPE_KUNIGAJO_3: case RM_TYPE_KOMUNAJO_3: return 3;
+    case RM_TYPE_KUNIGAJO_4: case RM_TYPE_KOMUNAJO_4: return 4;
+    default: return -1;
+    }
+}
+
+int node_floats(uint32_t type) {
+    switch (type) {
+    case RM_TYPE_PORTANTA_SFERO: case RM_TYPE_ROTACIOQ: return 4;
+    case RM_TYPE_KUBO: case RM_TYPE_EBENO: case RM_TYPE_MOVO: case RM_TYPE_SENFINA_RIPETO: return 3;
+    case RM_TYPE_CILINDRO: case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY: case RM_TYPE_ROTACIOZ: return 2;
+    case RM_TYPE_SFERO: case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: return 1;
+    default: return 0;
+    }
+}
+
+// --------------------------------------------------------------------- codecs
+
+// Payload structs (Include/objects_list.h:8-30): the child counters come first,
+// the floats follow; with `cw`-byte counters the floats start at arity*cw.
+int decode_bazo(const void* records, size_t n, int layout, rm_node* out) {
+    if ((!records || !out) && n) return RM_ERR_INVALID_ARG;
+    size_t type_at, data_at; int cw;
+    switch (layout) {
+    case RM_BAZO_LP64:  type_at = 0;  data_at = 4; cw = 8; break;
+    case RM_BAZO_LLP64: type_at = 0;  data_at = 4; cw = 4; break;
+    case RM_BAZO_SCE:   type_at = 40; data_at = 0; cw = 4; break;
+    default: return RM_ERR_INVALID_ARG;
+    }
+    const unsigned char* rec = static_cast<const unsigned char*>(records);
+    for (size_t i = 0; i < n; ++i, rec += RM_BAZO_BYTES) {
+        rm_node nd;
+        std::memset(&nd, 0, sizeof nd);
+        std::memcpy(&nd.type, rec + type_at, 4);
+        int na = node_arity(nd.type), nf = node_floats(nd.type);
+        if (na < 0) { out[i] = nd; continue; }      // nenio / unknown: kept, rejected if reachable
+        if (na * cw + nf * 4 > RM_PRIMITIVE_PAYLOAD) return RM_ERR_UNSUPPORTED;
+        const unsigned char* d = rec + data_at;
+        for (int k = 0; k < na; ++k) {
+            if (cw == 4) { int32_t v; std::memcpy(&v, d + 4 * k, 4); nd.o[k] = v; }
+            else {
+                int64_t v; std::memcpy(&v, d + 8 * k, 8);
+                if (v > INT32_MAX || v < INT32_MIN) return RM_ERR_BAD_SCENE;
+                nd.o[k] = static_cast<int32_t>(v);
+            }
+        }
+        std::memcpy(nd.f, d + na * cw, static_cast<size_t>(nf) * 4);
+        out[i] = nd;
+    }
+    return RM_OK;
+}
+
+void encode_sce(const rm_node* nodes, size_t n, std::vector<unsigned char>& bytes) {
+    bytes.assign(n * RM_BAZO_BYTES, 0);
+    for (size_t i = 0; i < n; ++i) {
+        unsigned char* rec = bytes.data() + i * RM_BAZO_BYTES;
+        int na = node_arity(nodes[i].type), nf = node_floats(nodes[i].type);
+        if (na < 0) na = 0;
+        std::memcpy(rec, nodes[i].o, static_cast<size_t>(na) * 4);
+        std::memcpy(rec + na * 4, nodes[i].f, static_cast<size_t>(nf) * 4);
+        std::memcpy(rec + 40, &nodes[i].type, 4);
+    }
+}
+
+int load_sce(const char* path, std::vector<rm_node>& out) {
+    if (!path) return RM_ERR_INVALID_ARG;
+    std::FILE* f = std::fopen(path, "rb");
+    if (!f) return RM_ERR_IO;
+    std::vector<unsigned char> bytes;
+    unsigned char buf[4096];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) bytes.insert(bytes.end(), buf, buf + got);
+    std::fclose(f);
+    if (bytes.empty() || bytes.size() % RM_BAZO_BYTES) return RM_ERR_IO;
+    out.resize(bytes.size() / RM_BAZO_BYTES);
+    return decode_bazo(bytes.data(), out.size(), RM_BAZO_SCE, out.data());
+}
+
+int save_sce(const char* path, const rm_node* nodes, size_t n) {
+    if (!path || (!nodes && n)) return RM_ERR_INVALID_ARG;
+    std::vector<unsigned char> bytes;
+    encode_sce(nodes, n, bytes);
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f) return RM_ERR_IO;
+    size_t put = std::fwrite(bytes.data(), 1, bytes.size(), f);
+    int rc = std::fclose(f);
+    return (put == bytes.size() && rc == 0) ? RM_OK : RM_ERR_IO;
+}
+
+// ------------------------------------------------------------------ flattener
+
+namespace {
+
+inline uint32_t fbits(float v) { uint32_t u; std::memcpy(&u, &v, 4); return u; }
+
+enum Src { SRC_P = 0, SRC_F = 1 };
+
+struct Flattener {
+    const rm_node* nodes;
+    size_t n;
+    std::vector<Slot> prog;
+    std::vector<unsigned char> seen;
+    uint32_t sp = 0, max_sp = 0;     // LDS stack depth in dwords
+    bool f_live = false;             // an enclosing combinator still needs F
+    bool b_live = false;             // register B holds a pushed value
+    long last_xf = -1;               // slot index of the transform that last wrote P
+    uint32_t depth = 0, max_depth = 0;
+    int err = RM_OK;
+
+    Slot& emit(uint32_t op, uint32_t flags = 0) {
+        Slot s; std::memset(&s, 0, sizeof s);
+        s.w[0] = op | flags;
+        prog.push_back(s);
+        last_xf = -1;
+        if (prog.size() > kMaxProgramSlots) err = RM_ERR_TOO_LARGE;
+        return prog.back();
+    }
+    uint32_t alloc(uint32_t dwords) {
+        uint32_t at = sp; sp += dwords; if (sp > max_sp) max_sp = sp; return at;
+    }
+
+    // komplemento* / at most one movo / primitive  ->  one fused slot
+    bool try_prim(size_t idx, Src src, uint32_t comb) {
+        bool neg = false, have_t = false;
+        float t[3] = {0.f, 0.f, 0.f};
+        size_t at = idx;
+        uint32_t hops = 0;
+        for (;;) {
+            const rm_node& nd = nodes[at];
+            if (nd.type == RM_TYPE_KOMPLEMENTO) { neg = !neg; }
+            else if (nd.type == RM_TYPE_MOVO && !have_t) { have_t = true; t[0] = nd.f[0]; t[1] = nd.f[1]; t[2] = nd.f[2]; }
+            else break;
+            at += static_cast<size_t>(nd.o[0]);
+            ++hops;
+        }
+        const rm_node& nd = nodes[at];
+        uint32_t op;
+        switch (nd.type) {
+        case RM_TYPE_SFERO: op = OP_SFERO; break;
+        case RM_TYPE_KUBO: op = OP_KUBO; break;
+        case RM_TYPE_CILINDRO: op = OP_CILINDRO; break;
+        case RM_TYPE_EBENO: op = OP_EBENO; break;
+        default: return false;
+        }
+        // a komplemento BELOW the movo negates the same value, so one flag covers
+        // every order in which the two kinds of wrapper were nested
+        Slot& s = emit(op, (src == SRC_F ? F_SRC_F : 0) | (neg ? F_NEG : 0) | (comb << F_COMB_SHIFT));
+        s.w[1] = fbits(t[0]); s.w[2] = fbits(t[1]); s.w[3] = fbits(t[2]);
+        for (int k = 0; k < node_floats(nd.type); ++k) s.w[4 + k] = fbits(nd.f[k]);
+        if (depth + hops + 1 > max_depth) max_depth = depth + hops + 1;
+        return true;
+    }
+
+    void push_a(bool& in_b, uint32_t& slot) {
+        if (!b_live) { b_live = true; in_b = true; slot = 0; emit(OP_PUSHA_R); }
+        else { in_b = false; slot = alloc(1); emit(OP_PUSHA, slot << F_SLOT_SHIFT); }
+    }
+    void pop_release(bool in_b) { if (in_b) b_live = false; else sp -= 1; }
+
+    // make F hold the point currently in `src`; returns the LDS slot F was saved to, or -1
+    long enter_frame(Src src) {
+        if (src == SRC_F) return -1;
+        if (f_live) {
+            uint32_t slot = alloc(3);
+            emit(OP_PUSHF, slot << F_SLOT_SHIFT);
+            return static_cast<long>(slot);
+        }
+        if (last_xf >= 0) { long at = last_xf; prog[static_cast<size_t>(at)].w[0] |= F_DST_F; last_xf = -1; }
+        else emit(OP_SETF);
+        return -1;
+    }
+    void leave_frame(long slot) {
+        if (slot >= 0) { emit(OP_POPF, static_cast<uint32_t>(slot) << F_SLOT_SHIFT); sp -= 3; }
+    }
+
+    bool descend(size_t idx) {
+        if (err) return false;
+        if (idx >= n) { err = RM_ERR_BAD_SCENE; return false; }
+        if (node_arity(nodes[idx].type) < 0) { err = RM_ERR_BAD_SCENE; return false; }
+        if (++depth > max_depth) max_depth = depth;
+        if (depth > kMaxTreeDepth) { err = RM_ERR_TOO_LARGE; return false; }
+        seen[idx] = 1;
+        return true;
+    }
+    size_t child(size_t idx, int k) {
+        int32_t o = nodes[idx].o[k];
+        if (o <= 0 || idx + static_cast<size_t>(o) >= n) { err = RM_ERR_BAD_SCENE; return idx; }
+        return idx + static_cast<size_t>(o);
+    }
+
+    // mark every node of a fused wrapper chain as reachable and check its links
+    bool check_chain(size_t idx) {
+        size_t at = idx;
+        for (uint32_t hops = 0;; ++hops) {
+            if (at >= n || node_arity(nodes[at].type) < 0 || depth + hops + 1 > kMaxTreeDepth) {
+                err = at >= n || node_arity(nodes[at].type) < 0 ? RM_ERR_BAD_SCENE : RM_ERR_TOO_LARGE;
+                return false;
+            }
+            seen[at] = 1;
+            if (node_arity(nodes[at].type) != 1) return true;
+            int32_t o = nodes[at].o[0];
+            if (o <= 0) { err = RM_ERR_BAD_SCENE; return false; }
+            uint32_t ty = nodes[at].type;
+            if (ty != RM_TYPE_KOMPLEMENTO && ty != RM_TYPE_MOVO) return true;
+            at += static_cast<size_t>(o);
+        }
+    }
+
+    // A = DIST(node idx, point in src)
+    void eval(size_t idx, Src src) {
+        if (err) return;
+        if (!check_chain(idx)) return;
+        if (try_prim(idx, src, COMB_SET)) return;
+        if (!descend(idx)) return;
+        const rm_node& nd = nodes[idx];
+        const uint32_t sflag = (src == SRC_F ? F_SRC_F : 0);
+        switch (nd.type) {
+        case RM_TYPE_KOMPLEMENTO:
+            eval(child(idx, 0), src);
+            emit(OP_NEG);
+            break;
+        case RM_TYPE_MOVO: {
+            Slot& s = emit(OP_MOVO, sflag);
+            s.w[1] = fbits(nd.f[0]); s.w[2] = fbits(nd.f[1]); s.w[3] = fbits(nd.f[2]);
+            last_xf = static_cast<long>(prog.size()) - 1;
+            eval(child(idx, 0), SRC_P);
+            break;
+        }
+        case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY: case RM_TYPE_ROTACIOZ: {
+            uint32_t op = nd.type == RM_TYPE_ROTACIOX ? OP_ROTX : nd.type == RM_TYPE_ROTACIOY ? OP_ROTY : OP_ROTZ;
+            Slot& s = emit(op, sflag);
+            s.w[1] = fbits(nd.f[0]); s.w[2] = fbits(nd.f[1]);
+            last_xf = static_cast<long>(prog.size()) - 1;
+            eval(child(idx, 0), SRC_P);
+            break;
+        }
+        case RM_TYPE_ROTACIOQ: {
+            float Q[9];
+            build_q(nd, Q);
+            emit(OP_ROTQ, sflag);
+            size_t at = prog.size() - 1;
+            emit(OP_END);                      // operand slot, never dispatched
+            for (int k = 0; k < 7; ++k) prog[at].w[1 + k] = fbits(Q[k]);
+            prog[at + 1].w[0] = fbits(Q[7]); prog[at + 1].w[1] = fbits(Q[8]);
+            last_xf = static_cast<long>(at);
+            eval(child(idx, 0), SRC_P);
+            break;
+        }
+        case RM_TYPE_SENFINA_RIPETO: {
+            Slot& s = emit(OP_RIPETO, sflag);
+            s.w[1] = fbits(nd.f[0]); s.w[2] = fbits(nd.f[1]); s.w[3] = fbits(nd.f[2]);
+            s.w[4] = fbits(nd.f[0] * nd.f[0] + nd.f[1] * nd.f[1] + nd.f[2] * nd.f[2]);
+            last_xf = static_cast<long>(prog.size()) - 1;
+            eval(child(idx, 0), SRC_P);
+            break;
+        }
+        case RM_TYPE_PORTANTA_SFERO: {
+            uint32_t slot = alloc(1);
+            Slot& s = emit(OP_PORTANTA, sflag | (slot << F_SLOT_SHIFT));
+            s.w[1] = fbits(nd.f[0]); s.w[2] = fbits(nd.f[1]); s.w[3] = fbits(nd.f[2]); s.w[4] = fbits(nd.f[3]);
+            size_t at = prog.size() - 1;
+            eval(child(idx, 0), SRC_P);
+            prog[at].w[5] = static_cast<uint32_t>(prog.size() - (at + 1));
+            emit(OP_PORTANTA_END, slot << F_SLOT_SHIFT);
+            sp -= 1;
+            break;
+        }
+        case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: {
+            long saved = enter_frame(src);
+            bool was_live = f_live; f_live = true;
+            eval(child(idx, 0), SRC_F);
+            bool in_b; uint32_t slot;
+            push_a(in_b, slot);
+            eval(child(idx, 1), SRC_F);
+            Slot& s = emit(in_b ? OP_GLATA_R : OP_GLATA,
+                           (nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? F_NEG : 0) | (slot << F_SLOT_SHIFT));
+            s.w[1] = fbits(nd.f[0]);
+            pop_release(in_b);
+            f_live = was_live;
+            leave_frame(saved);
+            break;
+        }
+        default: {   // kunigajo_N / komunajo_N
+            int na = node_arity(nd.type);
+            bool is_min = nd.type == RM_TYPE_KUNIGAJO_2 || nd.type == RM_TYPE_KUNIGAJO_3 || nd.type == RM_TYPE_KUNIGAJO_4;
+            long saved = enter_frame(src);
+            bool was_live = f_live; f_live = true;
+            eval(child(idx, 0), SRC_F);
+            for (int k = 1; k < na; ++k) accum(child(idx, k), is_min ? COMB_MIN : COMB_MAX);
+            f_live = was_live;
+            leave_frame(saved);
+            break;
+        }
+        }
+        --depth;
+    }
+
+    // A = comb(A, DIST(node idx, F))
+    void accum(size_t idx, uint32_t comb) {
+        if (err) return;
+        if (!check_chain(idx)) return;
+        if (try_prim(idx, SRC_F, comb)) return;
+        const uint32_t ty = idx < n ? nodes[idx].type : 0;
+        const bool same_kind =
+            (comb == COMB_MIN && (ty == RM_TYPE_KUNIGAJO_2 || ty == RM_TYPE_KUNIGAJO_3 || ty == RM_TYPE_KUNIGAJO_4)) ||
+            (comb == COMB_MAX && (ty == RM_TYPE_KOMUNAJO_2 || ty == RM_TYPE_KOMUNAJO_3 || ty == RM_TYPE_KOMUNAJO_4));
+        if (same_kind) {
+            // min(A, min(x, y)) == min(min(A, x), y): min and max are exact, so a
+            // nested combinator of the same kind continues the running chain
+            if (!descend(idx)) return;
+            int na = node_arity(ty);
+            for (int k = 0; k < na; ++k) accum(child(idx, k), comb);
+            --depth;
+            return;
+        }
+        bool in_b; uint32_t slot;
+        push_a(in_b, slot);
+        eval(idx, SRC_F);
+        emit(in_b ? OP_POPC_R : OP_POPC, (comb << F_COMB_SHIFT) | (slot << F_SLOT_SHIFT));
+        pop_release(in_b);
+    }
+
+    // Source/cuda_kernels.cu:504-525, same operations in the same order
+    static void build_q(const rm_node& nd, float Q[9]) {
+        const float qw = nd.f[0], qx = nd.f[1], qy = nd.f[2], qz = nd.f[3];
+        float xx = qx * qx, yy = qy * qy, zz = qz * qz, temp;
+        temp = xx + yy + zz;
+        xx -= temp; yy -= temp; zz -= temp;
+        float xy = qx * qy; temp = qz * qw; float yx = xy + temp; xy -= temp;
+        float yz = qy * qz; temp = qx * qw; float zy = yz + temp; yz -= temp;
+        float zx = qz * qx; temp = qy * qw; float xz = zx + temp; zx -= temp;
+        Q[0] = xx; Q[1] = xy; Q[2] = xz; Q[3] = yx; Q[4] = yy; Q[5] = yz; Q[6] = zx; Q[7] = zy; Q[8] = zz;
+    }
+
+    void build_tree(std::vector<TreeNode>& tree) {
+        tree.assign(n, TreeNode{});
+        for (size_t i = 0; i < n; ++i) {
+            if (!seen[i]) continue;
+            const rm_node& nd = nodes[i];
+            TreeNode& t = tree[i];
+            const int na = node_arity(nd.type);
+            auto kid = [&](int k) { return static_cast<uint32_t>(i + static_cast<size_t>(nd.o[k])); };
+            auto put = [&](int at, int count) { for (int k = 0; k < count; ++k) t.w[at + k] = fbits(nd.f[k]); };
+            uint32_t code = 0;
+            switch (nd.type) {
+            case RM_TYPE_PORTANTA_SFERO: code = TC_PORTANTA; t.w[1] = kid(0); put(2, 4); break;
+            case RM_TYPE_SFERO: code = TC_SFERO; put(1, 1); break;
+            case RM_TYPE_KUBO: code = TC_KUBO; put(1, 3); break;
+            case RM_TYPE_CILINDRO: code = TC_CILINDRO; put(1, 2); break;
+            case RM_TYPE_EBENO: code = TC_EBENO; put(1, 3); break;
+            case RM_TYPE_KUNIGAJO_2: case RM_TYPE_KUNIGAJO_3: case RM_TYPE_KUNIGAJO_4:
+                code = TC_KUNIGAJO; for (int k = 0; k < na; ++k) t.w[1 + k] = kid(k); break;
+            case RM_TYPE_KOMUNAJO_2: case RM_TYPE_KOMUNAJO_3: case RM_TYPE_KOMUNAJO_4:
+                code = TC_KOMUNAJO; for (int k = 0; k < na; ++k) t.w[1 + k] = kid(k); break;
+            case RM_TYPE_KOMPLEMENTO: code = TC_KOMPLEMENTO; t.w[1] = kid(0); break;
+            case RM_TYPE_GLATA_KUNIGAJO_2: code = TC_GLATA_KUNIGAJO; t.w[1] = kid(0); t.w[2] = kid(1); put(3, 1); break;
+            case RM_TYPE_GLATA_KOMUNAJO_2: code = TC_GLATA_KOMUNAJO; t.w[1] = kid(0); t.w[2] = kid(1); put(3, 1); break;
+            case RM_TYPE_MOVO: code = TC_MOVO; t.w[1] = kid(0); put(2, 3); break;
+            case RM_TYPE_ROTACIOX: code = TC_ROTX; t.w[1] = kid(0); put(2, 2); break;
+            case RM_TYPE_ROTACIOY: code = TC_ROTY; t.w[1] = kid(0); put(2, 2); break;
+            case RM_TYPE_ROTACIOZ: code = TC_ROTZ; t.w[1] = kid(0); put(2, 2); break;
+            case RM_TYPE_ROTACIOQ: {
+                code = TC_ROTQ; t.w[1] = kid(0);
+                float Q[9]; build_q(nd, Q);
+                for (int k = 0; k < 9; ++k) t.w[2 + k] = fbits(Q[k]);
+                break;
+            }
+            case RM_TYPE_SENFINA_RIPETO:
+                code = TC_RIPETO; t.w[1] = kid(0); put(2, 3);
+                t.w[5] = fbits(nd.f[0] * nd.f[0] + nd.f[1] * nd.f[1] + nd.f[2] * nd.f[2]);
+                break;
+            default: break;
+            }
+            t.w[0] = code | (static_cast<uint32_t>(na) << 8);
+        }
+    }
+};
+
+}  // namespace
+
+int build_scene(const rm_node* nodes, size_t n, SceneBuild& out) {
+    if (!nodes || n == 0) return RM_ERR_INVALID_ARG;
+    if (n > RM_MAX_NODES) return RM_ERR_TOO_LARGE;
+    Flattener fl;
+    fl.nodes = nodes; fl.n = n;
+    fl.seen.assign(n, 0);
+    fl.eval(0, SRC_F);
+    if (fl.err) return fl.err;
+    fl.emit(OP_END);
+    if (fl.err) return fl.err;
+    out.program.swap(fl.prog);
+    out.value_slots = fl.max_sp;
+    out.tree_depth = fl.max_depth;
+    out.reachable = 0;
+    for (unsigned char s : fl.seen) out.reachable += s;
+    fl.build_tree(out.tree);
+    out.seen = fl.seen;
+    return RM_OK;
+}
+
+std::string disassemble(const std::vector<Slot>& program) {
+    static const char* names[OP_COUNT] = {
+        "END", "MOVO", "ROTX", "ROTY", "ROTZ", "ROTQ", "RIPETO", "SETF",
+        "SFERO", "KUBO", "CILINDRO", "EBENO",
+        "PUSHA_R", "POPC_R", "PUSHA", "POPC", "NEG", "GLATA_R", "GLATA",
+        "PUSHF", "POPF", "PORTANTA", "PORTANTA_END" };
+    static const char* combs[4] = { "set", "min", "max", "?" };
+    std::string s;
+    char line[256];
+    for (size_t pc = 0; pc < program.size(); ++pc) {
+        const uint32_t w0 = program[pc].w[0];
+        const uint32_t op = w0 & 0xff;
+        float f[7];
+        std::memcpy(f, &program[pc].w[1], sizeof f);
+        std::snprintf(line, sizeof line, "%4zu %-12s src=%c dst=%c%s comb=%s slot=%u  %g %g %g %g %g %g %g\n",
+                      pc, op < OP_COUNT ? names[op] : "?", (w0 & F_SRC_F) ? 'F' : 'P', (w0 & F_DST_F) ? 'F' : 'P',
+                      (w0 & F_NEG) ? " neg" : "", combs[(w0 & F_COMB_MASK) >> F_COMB_SHIFT], w0 >> F_SLOT_SHIFT,
+                      f[0], f[1], f[2], f[3], f[4], f[5], f[6]);
+        s += line;
+        if (op == OP_END) break;
+        if (op == OP_ROTQ) ++pc;
+    }
+    return s;
+}
+
+}  // namespace rm

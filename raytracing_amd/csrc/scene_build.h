@@ -1,0 +1,42 @@
+// scene_build.h - host-side scene handling: record codecs, validation, and the
+// flattener that produces the two device forms declared in scene_program.h.
+#pragma once
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "../../include/raymarching_amd.h"
+#include "scene_program.h"
+
+namespace rm {
+
+// Longest root-to-leaf path the per-lane tree walker's private stack can hold.
+constexpr uint32_t kMaxTreeDepth = 64;
+// Upper bound on distance-program slots (a node shared by several parents is
+// emitted once per path, so a DAG can expand).
+constexpr uint32_t kMaxProgramSlots = 1u << 16;
+
+struct SceneBuild {
+    std::vector<TreeNode> tree;      // one per input node (unreachable ones zeroed)
+    std::vector<Slot>     program;   // distance program, terminated by OP_END
+    uint32_t value_slots = 0;        // per-lane LDS stack dwords the program needs
+    uint32_t tree_depth  = 0;
+    uint32_t reachable   = 0;
+    std::vector<unsigned char> seen; // 1 for nodes reachable from node 0
+};
+
+int  node_arity(uint32_t type);      // child links, -1 for nenio/unknown
+int  node_floats(uint32_t type);     // payload floats
+
+int  decode_bazo(const void* records, size_t n, int layout, rm_node* out);
+void encode_sce(const rm_node* nodes, size_t n, std::vector<unsigned char>& bytes);
+int  load_sce(const char* path, std::vector<rm_node>& out);
+int  save_sce(const char* path, const rm_node* nodes, size_t n);
+
+// Validate and flatten.  Returns an rm_status.
+int  build_scene(const rm_node* nodes, size_t n, SceneBuild& out);
+
+// Human-readable listing of a distance program (tests).
+std::string disassemble(const std::vector<Slot>& program);
+
+}  // namespace rm

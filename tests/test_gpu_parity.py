@@ -1,0 +1,219 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+restatement (oracle/) on the same inputs.  Bar: bit-exact.
+
+The kernels use IEEE fp32 add/mul/div/sqrt without contraction in the
+reference's operation order, so no tolerance is needed or allowed here:
+frames must be byte-identical (north_star allows <=1 LSB per channel and
+counted grazing-pixel mask flips; we measure 0 of either).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import kat_scenes
+from oracle import oracle as O
+from raytracing_amd import api, scenes
+
+pytestmark = pytest.mark.gpu
+
+# sha256 of the P6 PPM the reference's march produced host-side
+GOLDEN_PPM = {
+    "chair": "f5c226d07e78e48b447e0456fc75922d8fe8f0794e9569cfc7b5efabfea489ec",
+    "infinity": "369094d61c29b3a505f77cde384c40af3c8b427acc609ecc5ca01086ac6a59e8",
+}
+GOLDEN_HITS = {("chair", 640, 480): 259549, ("infinity", 640, 480): 307136,
+               ("chair", 1920, 1080): 296418, ("infinity", 1920, 1080): 2073420}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def same_floats(a, b):
+    """bit-identical, except that +0 and -0 compare equal (the program
+    re-associates exact min/max chains, which can only change the sign of a zero)
+    and that any NaN equals any NaN (an invalid operation yields 0xFFC00000 on
+    x86 and 0x7FC00000 on gfx950; e.g. the normalised normal on a cylinder's axis)"""
+    fa, fb = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    a, b = bits(a), bits(b)
+    return np.all((a == b) | (((a | b) & 0x7FFFFFFF) == 0) | (np.isnan(fa) & np.isnan(fb)))
+
+
+def gpu_render(nodes, w, h, info, evaluator=0, norm_batch=None):
+    with api.Raymarching(w, h) as rm:
+        rm.set_nodes(nodes)
+        rm.set_info(info)
+        rm.enable_hit_mask(True)
+        rm.set_evaluator(evaluator)
+        if norm_batch is not None:
+            rm.set_norm_batch(norm_batch)
+        ms = rm.process()
+        return rm.read_pixels(), rm.read_hit_mask(), ms
+
+
+@pytest.mark.parametrize("name", sorted(kat_scenes.SCENES))
+def test_node_kat(name):
+    """DIST and NORM of every node type / flattener path at seeded points."""
+    table = kat_scenes.tables()[name]
+    pts = kat_scenes.points()
+    want_d = O.dist_many(table, 0, pts)
+    want_n = O.norm_many(table, 0, pts)
+    with api.Raymarching(64, 64) as rm:
+        rm.set_nodes(table)
+        d_prog, _ = rm.eval_points(pts, 0, which=0, want_norm=False)
+        d_walk, n_walk = rm.eval_points(pts, 0, which=1, want_norm=True)
+    assert same_floats(d_walk, want_d), "tree walker DIST differs from the oracle"
+    assert same_floats(d_prog, want_d), "distance program DIST differs from the oracle"
+    assert same_floats(n_walk, want_n), "tree walker NORM differs from the oracle"
+
+
+def test_node_kat_inner_nodes():
+    """The walker can start at any reachable node (sub-tree evaluation)."""
+    table = kat_scenes.tables()["nested_frames"]
+    pts = kat_scenes.points(64)
+    with api.Raymarching(64, 64) as rm:
+        rm.set_nodes(table)
+        for idx in range(len(table)):
+            d, n = rm.eval_points(pts, idx, which=1)
+            assert same_floats(d, O.dist_many(table, idx, pts)), idx
+            assert same_floats(n, O.norm_many(table, idx, pts)), idx
+
+
+def test_set_rays_kat():
+    """kernel_SetRays (Source/cuda_kernels.cu:730-762) fused into the kernel."""
+    for (w, h, phi) in [(640, 480, 0), (1920, 1080, 37), (7680, 4320, 119), (33, 17, 5)]:
+        info = O.default_info(1, phi)
+        rng = np.random.default_rng(w)
+        xy = np.stack([rng.integers(0, w, 256), rng.integers(0, h, 256)], axis=1).astype(np.int32)
+        xy[:4] = [[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1]]
+        with api.Raymarching(w, h) as rm:
+            rm.set_info(info)
+            got = rm.eval_rays(xy)
+        want = np.stack([O.set_ray(w, h, info, int(x), int(y)) for x, y in xy])
+        assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("name", ["chair", "infinity"])
+@pytest.mark.parametrize("evaluator", [0, 1])
+def test_stock_frame_640x480(stock_scenes, name, evaluator):
+    """SURVEY.md 8d config 1 on the GPU: byte-identical frame, golden sha256, hit count."""
+    info = O.default_info(1, 0)
+    rgba, hit, _ = gpu_render(stock_scenes[name], 640, 480, info, evaluator)
+    ref = O.render(stock_scenes[name], 640, 480, info, threads=os.cpu_count() or 4)
+    assert int(hit.sum()) == GOLDEN_HITS[(name, 640, 480)]
+    assert np.array_equal(hit, ref["hit"]), "hit mask differs: %d px" % int((hit != ref["hit"]).sum())
+    assert np.array_equal(rgba, ref["rgba"]), "colour differs: %d px" % int((rgba != ref["rgba"]).any(-1).sum())
+    assert hashlib.sha256(O.ppm_bytes(rgba)).hexdigest() == GOLDEN_PPM[name]
+    # q6: the explicit hit bit and the colour-derived mask agree on the stock scenes
+    assert np.array_equal(hit.astype(bool), rgba[:, :, :3].any(-1))
+
+
+@pytest.mark.parametrize("name", ["chair", "infinity"])
+def test_stock_hits_1080p(stock_scenes, name):
+    """config 2: hit count recorded from the reference's host-side run at 1920x1080."""
+    info = O.default_info(1, 0)
+    rgba, hit, _ = gpu_render(stock_scenes[name], 1920, 1080, info)
+    assert int(hit.sum()) == GOLDEN_HITS[(name, 1920, 1080)]
+    # rows sampled across the frame, byte-for-byte against the oracle
+    for y0 in (0, 270, 536, 540, 812, 1079):
+        ref = O.render(stock_scenes[name], 1920, 1080, info, rows=(y0, y0 + 1))
+        assert np.array_equal(rgba[y0], ref["rgba"][y0]), y0
+        assert np.array_equal(hit[y0], ref["hit"][y0]), y0
+
+
+def test_norm_batch_does_not_change_pixels(stock_scenes):
+    info = O.default_info(1, 0)
+    base, hit0, _ = gpu_render(stock_scenes["chair"], 320, 240, info, norm_batch=1)
+    for batch in (8, 64):
+        rgba, hit, _ = gpu_render(stock_scenes["chair"], 320, 240, info, norm_batch=batch)
+        assert np.array_equal(rgba, base) and np.array_equal(hit, hit0)
+
+
+def test_csg1024_frame():
+    """config 4's 1024-record table (beyond the reference's 256-slot limit) at a
+    size the oracle finishes in seconds."""
+    table = scenes.csg1024()
+    info = O.default_info(1, 0)
+    w, h = 256, 144
+    rgba, hit, _ = gpu_render(table, w, h, info)
+    ref = O.render(table, w, h, info, threads=os.cpu_count() or 4)
+    assert ref["hit"].sum() > 0
+    assert np.array_equal(hit, ref["hit"])
+    assert np.array_equal(rgba, ref["rgba"])
+    rgba_w, hit_w, _ = gpu_render(table, w, h, info, evaluator=1)
+    assert np.array_equal(rgba_w, rgba) and np.array_equal(hit_w, hit)
+
+
+@pytest.mark.parametrize("name", ["mixed_kinds", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
+def test_kat_scene_frames(name):
+    """Whole frames of the nested test scenes (LDS value slots, saved frames, bounding spheres)."""
+    table = kat_scenes.tables()[name]
+    info = O.default_info(3, 11)
+    info["StartPos"] = (-40.0, 3.0, 2.0)
+    w, h = 200, 120
+    rgba, hit, _ = gpu_render(table, w, h, info)
+    ref = O.render(table, w, h, info, threads=os.cpu_count() or 4)
+    assert np.array_equal(hit, ref["hit"])
+    assert np.array_equal(rgba, ref["rgba"])
+
+
+def test_ragged_sizes(stock_scenes):
+    """Image sizes that are not multiples of the 16x16 workgroup block."""
+    info = O.default_info(1, 0)
+    for (w, h) in [(1, 1), (17, 9), (250, 131)]:
+        rgba, hit, _ = gpu_render(stock_scenes["chair"], w, h, info)
+        ref = O.render(stock_scenes["chair"], w, h, info)
+        assert np.array_equal(rgba, ref["rgba"]) and np.array_equal(hit, ref["hit"])
+
+
+def test_row_bands_reassemble(stock_scenes):
+    """Multi-GPU partition on one GPU: every rank's bands, interleaved back, equal the whole frame."""
+    from raytracing_amd import tiling
+    info = O.default_info(1, 0)
+    w, h = 320, 250
+    whole, _, _ = gpu_render(stock_scenes["chair"], w, h, info)
+    for nranks, band in [(2, 16), (3, 32), (8, 16)]:
+        parts = []
+        for rank in range(nranks):
+            with api.Raymarching(w, h) as rm:
+                rm.set_nodes(stock_scenes["chair"])
+                rm.set_info(info)
+                rm.set_bands(band, rank, nranks)
+                assert rm.local_rows() == tiling.local_rows(h, band, rank, nranks)
+                rm.process()
+                parts.append(rm.read_pixels())
+        frame = tiling.assemble(parts, h, band)
+        assert np.array_equal(frame, whole)
+
+
+def test_external_output_and_pitch(stock_scenes):
+    """rm_set_output: render into a caller-owned device buffer with a padded pitch."""
+    torch = pytest.importorskip("torch")
+    info = O.default_info(1, 0)
+    w, h, pitch = 100, 60, 512
+    buf = torch.zeros((h, pitch), dtype=torch.uint8, device="cuda:0")
+    with api.Raymarching(w, h) as rm:
+        rm.set_nodes(stock_scenes["chair"])
+        rm.set_info(info)
+        rm.set_output(buf.data_ptr(), pitch)
+        rm.set_stream(torch.cuda.current_stream().cuda_stream)
+        rm.process()
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()[:, : w * 4].reshape(h, w, 4)
+    ref = O.render(stock_scenes["chair"], w, h, info)
+    assert np.array_equal(got, ref["rgba"])
+    assert not buf.cpu().numpy()[:, w * 4:].any(), "bytes beyond width*4 must stay untouched"
+
+
+def test_errors_are_reported(stock_scenes):
+    with api.Raymarching(64, 64) as rm:
+        with pytest.raises(api.RaymarchError) as e:
+            rm.process()                      # nothing set yet
+        assert e.value.status == -6
+        bad = stock_scenes["chair"].copy()
+        bad[4]["type"] = 0                    # nenio reachable: the reference would call a null pointer
+        with pytest.raises(api.RaymarchError) as e:
+            rm.set_nodes(bad)
+        assert e.value.status == -2
