@@ -1,0 +1,143 @@
+// main.cpp - headless front end: the reference's `--width/--height/--input`
+// command line (Source/main.cpp:12-39) driving the HIP backend through the same
+// call sequence (Source/main.cpp:67-138, 261-270, 292-293), with a PPM dump in
+// the place of the SDL window.
+//
+//   rm_render --width W --height H [--input scene.sce] [--frames K] [--out frame.ppm] [--device D]
+//
+// Without --input the scene hard-coded in Source/main.cpp:86-123 is built with
+// the same create_from calls.  Without --width/--height the reference takes the
+// display size (Source/main.cpp:46-47); headless, 1920x1080 stands in for it.
+// As in the reference a size flag given twice toggles itself off again
+// (`correctInit ^= ...`, Source/main.cpp:25,28) and falls back to that default.
+#include <bitset>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "rays.hpp"
+
+constexpr float M_SQRT1_5f{ .447213595499957939281f };   // Source/main.cpp:7
+
+using namespace std;
+
+static int write_ppm(const string& path, const vector<unsigned char>& rgba, size_t w, size_t h) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return -1;
+    fprintf(f, "P6\n%zu %zu\n255\n", w, h);
+    vector<unsigned char> row(w * 3);
+    for (size_t y = 0; y < h; ++y) {
+        for (size_t x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) row[x * 3 + c] = rgba[(y * w + x) * 4 + c];
+        fwrite(row.data(), 1, row.size(), f);
+    }
+    return fclose(f);
+}
+
+int main(int argc, char** argv) {
+    size_t Width = 0, Height = 0, Frames = 1;
+    int Device = 0;
+    string File, Out;
+
+    string arg;
+    bitset<3> correctInit;
+    for (int I = 1; I < argc; ++I) {
+        arg = argv[I];
+        if (arg.substr(0, 2) != "--" || I + 1 >= argc) continue;
+        arg = arg.substr(2);
+        if (arg == "width")        { Width = atoi(argv[++I]);  if (Width)  correctInit ^= 1 << 0; }
+        else if (arg == "height")  { Height = atoi(argv[++I]); if (Height) correctInit ^= 1 << 1; }
+        else if (arg == "input")   { File = argv[++I];         if (File.size()) correctInit ^= 1 << 2; }
+        else if (arg == "frames")  { Frames = strtoul(argv[++I], nullptr, 10); }
+        else if (arg == "out")     { Out = argv[++I]; }
+        else if (arg == "device")  { Device = atoi(argv[++I]); }
+    }
+    if (!correctInit[0]) Width = 1920;
+    if (!correctInit[1]) Height = 1080;
+
+    null::raymarching* HIP = new hip::raymarching(Device);
+    hip::raymarching* backend = static_cast<hip::raymarching*>(HIP);
+    if (int rc = HIP->Init(Width, Height)) {
+        cerr << "Init failed: " << rc << " (" << rm_status_string(rc) << ")" << endl;
+        return 1;
+    }
+    HIP->SetTexture(0);
+
+    if (correctInit[2]) {
+        if (int rc = backend->LoadScene(File.c_str())) {
+            cerr << "cannot load " << File << ": " << rc << " (" << rm_status_string(rc) << ")" << endl;
+            return 1;
+        }
+    } else {
+        // Source/main.cpp:86-123
+        point d{ 1.f, 30.f, 1.f };
+        float alpha = -1.8f, w = cosf(alpha / 2.f), r = sinf(alpha / 2.f) / sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+        HIP->ReservePrimitives(RAYS_BLOCK_2D_x * RAYS_BLOCK_2D_y * RAYS_PRIMITIVES_PER_THREAD);
+        HIP->AddPrimitive(primitives::senfina_ripeto::create_from({ 1, { 0.f, 500.f, 100.f } }));
+        HIP->AddPrimitive(primitives::movo::create_from({ 1, { 200.f, 0.f, 0.f } }));
+        HIP->AddPrimitive(primitives::rotacioQ::create_from({ 1, w, { r * d.x, r * d.y, r * d.z } }));
+        HIP->AddPrimitive(primitives::komunajo_3::create_from({ { 1, 2, 5 } }));
+        HIP->AddPrimitive(primitives::kubo::create_from({ { 50.f, 50.f, 50.f } }));
+        HIP->AddPrimitive(primitives::komplemento::create_from({ 1 }));
+        HIP->AddPrimitive(primitives::movo::create_from({ 1, { 0.f, 0.f, -50.f } }));
+        HIP->AddPrimitive(primitives::sfero::create_from({ 60.f }));
+        HIP->AddPrimitive(primitives::komplemento::create_from({ 1 }));
+        HIP->AddPrimitive(primitives::movo::create_from({ 1, { 0.f, 0.f, 50.f } }));
+        HIP->AddPrimitive(primitives::sfero::create_from({ 40.f }));
+        if (int rc = HIP->SetPrimitives()) {
+            cerr << "SetPrimitives failed: " << rc << " (" << rm_status_string(rc) << ")" << endl;
+            return 1;
+        }
+    }
+
+    // Source/main.cpp:127-138
+    float scale = powf(2.f, -6.1f), cos_theta = 1.f, sin_theta = 0.f, cos_phi = 1.f, sin_phi = 0.f;
+    float cos_1 = cosf(M_PI / 180.f), sin_1 = sinf(M_PI / 180.f);
+    rays_info Info_h{};
+    Info_h.Depth = 1000;
+    Info_h.LightSource = point{ -2.f * M_SQRT1_5f, 0.f, M_SQRT1_5f };
+    Info_h.StartPos = point{ 0.f, 0.f, 0.f };
+    Info_h.StartDir = point{ scale * cos_theta * cos_phi, scale * cos_theta * sin_phi, scale * sin_theta };
+    Info_h.StartWVec = point{ scale * sin_phi, -scale * cos_phi, 0.f };
+    Info_h.StartHVec = point{ scale * sin_theta * cos_phi, scale * sin_theta * sin_phi, -scale * cos_theta };
+    HIP->SetInfo(Info_h);
+
+    double kernel_ms = 0.0;
+    auto t0 = chrono::steady_clock::now();
+    for (size_t frame = 0; frame < Frames; ++frame) {
+        auto f0 = chrono::steady_clock::now();
+        // Source/main.cpp:261-266: the light turns one degree before every render
+        Info_h.LightSource = point{
+            cos_1 * Info_h.LightSource.x - sin_1 * Info_h.LightSource.y,
+            sin_1 * Info_h.LightSource.x + cos_1 * Info_h.LightSource.y,
+            Info_h.LightSource.z };
+        HIP->SetInfo(Info_h);
+        size_t compute_time = HIP->Process();
+        if (backend->LastStatus()) {
+            cerr << "\nProcess failed: " << backend->LastStatus() << " (" << rm_status_string(backend->LastStatus()) << ")" << endl;
+            return 1;
+        }
+        kernel_ms += backend->ProcessTime();
+        auto f1 = chrono::steady_clock::now();
+        cout << "\rFrame time : " << chrono::duration_cast<chrono::milliseconds>(f1 - f0).count()
+             << "ms  \t\tTask execution time : " << compute_time << "ms  " << flush;   // Source/main.cpp:287
+    }
+    double secs = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
+    cout << endl << Frames << " frame(s) " << Width << "x" << Height << ": " << (Width * Height * Frames / secs / 1e6)
+         << " Mrays/s wall, kernel " << (kernel_ms / Frames) << " ms/frame" << endl;
+
+    if (!Out.empty()) {
+        vector<unsigned char> rgba;
+        if (backend->ReadPixels(rgba) || write_ppm(Out, rgba, Width, Height)) {
+            cerr << "cannot write " << Out << endl;
+            return 1;
+        }
+    }
+    HIP->UnsetTexture();
+    HIP->Quit();
+    delete HIP;
+    return 0;
+}

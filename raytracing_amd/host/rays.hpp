@@ -1,0 +1,207 @@
+// rays.hpp - host-side mirror of the reference's backend interface, so that the
+// call sequence of its front end (Source/main.cpp:67-138,269-270,292-293) compiles
+// against this backend unchanged:
+//
+//   null::raymarching   abstract interface            (Include/rays.h:15-69)
+//   hip::raymarching    concrete backend over the C ABI, in the place of
+//                       cuda::raymarching             (Include/cuda_rays.cuh:14-46)
+//   primitives::TYPE::create_from({...})  node builders (Include/defines.h:17-27,
+//                       Include/objects_list.h:8-30, Include/types.h:56-72)
+//
+// Same names, argument meaning and return conventions: every method returns 0 on
+// success or the backend's status, except Process(), which returns the kernel
+// time in whole milliseconds (Include/rays.h:31-35, Source/cuda_rays.cu:215).
+// SetTexture takes a GL texture name in the reference; this backend is headless,
+// so it accepts the name and renders to its own linear RGBA8 framebuffer, which
+// ReadPixels() copies out.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/raymarching_amd.h"
+
+// ---- data model (Include/types.h:3-19) ----------------------------------------
+typedef unsigned char raw_byte;
+typedef long long     coord;
+#ifdef RM_COUNTER_32
+typedef int           counter;   // the reference's own LLP64 target: 4-byte child links
+#else
+typedef long          counter;   // Include/types.h:5 as it compiles on LP64
+#endif
+typedef float         scalar;
+typedef rm_point      point;
+typedef rm_ray        ray;
+typedef rm_rays_info  rays_info;
+
+#define RAYS_BLOCK_2D_x             16   // Include/defines.h:82-87: main.cpp:89 sizes its
+#define RAYS_BLOCK_2D_y             8    // reservation with these
+#define RAYS_PRIMITIVES_PER_THREAD  2
+
+namespace primitives {
+
+enum object_type : uint32_t {            // Include/types.h:29-54
+    type_nenio = RM_TYPE_NENIO,
+    type_portanta_sfero = RM_TYPE_PORTANTA_SFERO, type_sfero = RM_TYPE_SFERO, type_kubo = RM_TYPE_KUBO,
+    type_cilindro = RM_TYPE_CILINDRO, type_ebeno = RM_TYPE_EBENO,
+    type_kunigajo_2 = RM_TYPE_KUNIGAJO_2, type_kunigajo_3 = RM_TYPE_KUNIGAJO_3, type_kunigajo_4 = RM_TYPE_KUNIGAJO_4,
+    type_komunajo_2 = RM_TYPE_KOMUNAJO_2, type_komunajo_3 = RM_TYPE_KOMUNAJO_3, type_komunajo_4 = RM_TYPE_KOMUNAJO_4,
+    type_komplemento = RM_TYPE_KOMPLEMENTO,
+    type_glata_kunigajo_2 = RM_TYPE_GLATA_KUNIGAJO_2, type_glata_komunajo_2 = RM_TYPE_GLATA_KOMUNAJO_2,
+    type_movo = RM_TYPE_MOVO, type_rotacioX = RM_TYPE_ROTACIOX, type_rotacioY = RM_TYPE_ROTACIOY,
+    type_rotacioZ = RM_TYPE_ROTACIOZ, type_rotacioQ = RM_TYPE_ROTACIOQ, type_senfina_ripeto = RM_TYPE_SENFINA_RIPETO
+};
+
+// Include/types.h:56-61.  dist/norm are kept for layout only: this backend binds
+// node behaviour while flattening, not through function pointers.
+struct bazo {
+    object_type type;
+    raw_byte    data[RM_PRIMITIVE_PAYLOAD];
+    void*       dist;
+    void*       norm;
+};
+static_assert(sizeof(bazo) == RM_BAZO_BYTES, "bazo is a 48-byte record");
+
+// One node type: its payload struct and the create_from builder.  Unlike
+// Include/types.h:64-72 the unused payload bytes are zeroed, and a payload that
+// does not fit the 24 bytes (kunigajo_4 / komunajo_4 with 8-byte counters) is a
+// compile-time error instead of a silent overrun into `dist`.
+template <object_type Type, typename Payload>
+struct node_type {
+    typedef Payload data_struct;
+    static bazo create_from(data_struct data) {
+        static_assert(sizeof(data_struct) <= RM_PRIMITIVE_PAYLOAD,
+                      "payload exceeds PRIMITIVE_PAYLOAD: build with -DRM_COUNTER_32 for the *_4 combinators");
+        bazo b;
+        std::memset(&b, 0, sizeof b);
+        b.type = Type;
+        std::memcpy(b.data, &data, sizeof data);
+        return b;
+    }
+};
+
+// Include/objects_list.h:8-30
+struct portanta_sfero_data { counter o; point t; scalar r; };
+struct sfero_data          { scalar r; };
+struct kubo_data           { point b; };
+struct cilindro_data       { scalar r; scalar h; };
+struct ebeno_data          { point n; };
+template <int N> struct links_data { counter o[N]; };
+struct komplemento_data    { counter o; };
+struct glata_data          { counter o[2]; scalar k; };
+struct movo_data           { counter o; point t; };
+struct rotacio_data        { counter o; scalar cos_phi; scalar sin_phi; };
+struct rotacioQ_data       { counter o; scalar q_w; point q; };
+struct ripeto_data         { counter o; point a; };
+
+typedef node_type<type_portanta_sfero, portanta_sfero_data> portanta_sfero;
+typedef node_type<type_sfero, sfero_data>                   sfero;
+typedef node_type<type_kubo, kubo_data>                     kubo;
+typedef node_type<type_cilindro, cilindro_data>             cilindro;
+typedef node_type<type_ebeno, ebeno_data>                   ebeno;
+typedef node_type<type_kunigajo_2, links_data<2>>           kunigajo_2;
+typedef node_type<type_kunigajo_3, links_data<3>>           kunigajo_3;
+typedef node_type<type_kunigajo_4, links_data<4>>           kunigajo_4;
+typedef node_type<type_komunajo_2, links_data<2>>           komunajo_2;
+typedef node_type<type_komunajo_3, links_data<3>>           komunajo_3;
+typedef node_type<type_komunajo_4, links_data<4>>           komunajo_4;
+typedef node_type<type_komplemento, komplemento_data>       komplemento;
+typedef node_type<type_glata_kunigajo_2, glata_data>        glata_kunigajo_2;
+typedef node_type<type_glata_komunajo_2, glata_data>        glata_komunajo_2;
+typedef node_type<type_movo, movo_data>                     movo;
+typedef node_type<type_rotacioX, rotacio_data>              rotacioX;
+typedef node_type<type_rotacioY, rotacio_data>              rotacioY;
+typedef node_type<type_rotacioZ, rotacio_data>              rotacioZ;
+typedef node_type<type_rotacioQ, rotacioQ_data>             rotacioQ;
+typedef node_type<type_senfina_ripeto, ripeto_data>         senfina_ripeto;
+
+}  // namespace primitives
+
+namespace null {
+
+// Include/rays.h:15-69
+class raymarching {
+protected:
+    size_t Width = 0, Height = 0;
+    std::string SceneName;
+    std::vector<primitives::bazo> Primitives_h;
+    size_t PrimitivesNum = 0;
+
+public:
+    virtual ~raymarching() {}
+    virtual int Init(const size_t& width, const size_t& height) = 0;
+    virtual int Process() = 0;
+    virtual int Quit() = 0;
+    virtual int SetInfo(const rays_info& info) = 0;
+    virtual int SetTexture(unsigned int texture) = 0;
+    virtual int UnsetTexture() = 0;
+    virtual int SetPrimitives() = 0;
+    virtual int SetRays() = 0;
+
+    inline void SetSceneName(const char* name) { SceneName = name; }
+    inline void ReservePrimitives(size_t new_capacity) { Primitives_h.reserve(new_capacity); PrimitivesNum = 0; }
+    inline void AddPrimitive(primitives::bazo new_primitive) { Primitives_h.push_back(new_primitive); PrimitivesNum++; }
+    inline void ClearPrimitives() { Primitives_h.clear(); PrimitivesNum = 0; }
+};
+
+}  // namespace null
+
+namespace hip {
+
+class raymarching : public null::raymarching {
+    rm_ctx* ctx_ = nullptr;
+    int device_ = 0;
+    int last_ = RM_OK;
+    float last_ms_ = 0.f;
+
+public:
+    explicit raymarching(int device = 0) : device_(device) {}
+    ~raymarching() override { if (ctx_) rm_destroy(ctx_); }
+
+    int Init(const size_t& width, const size_t& height) override {
+        Width = width; Height = height;
+        if (ctx_) { rm_destroy(ctx_); ctx_ = nullptr; }
+        return last_ = rm_create(device_, width, height, &ctx_);
+    }
+    // whole milliseconds like the reference; ProcessTime() has the float
+    int Process() override {
+        last_ = rm_process(ctx_, &last_ms_);
+        return last_ == RM_OK ? static_cast<int>(static_cast<uint32_t>(last_ms_)) : 0;
+    }
+    int Quit() override {
+        int rc = ctx_ ? rm_destroy(ctx_) : RM_OK;
+        ctx_ = nullptr;
+        return last_ = rc;
+    }
+    int SetInfo(const rays_info& info) override { return last_ = rm_set_info(ctx_, &info); }   // SetRays is fused
+    int SetTexture(unsigned int) override { return last_ = rm_set_output(ctx_, nullptr, 0); }
+    int UnsetTexture() override { return last_ = RM_OK; }
+    int SetPrimitives() override {
+        PrimitivesNum = Primitives_h.size();
+        return last_ = rm_set_primitives(ctx_, Primitives_h.data(), PrimitivesNum,
+                                         sizeof(counter) == 8 ? RM_BAZO_LP64 : RM_BAZO_LLP64);
+    }
+    int SetRays() override { return last_ = RM_OK; }   // rays are derived inside Process()
+
+    // ---- beyond the reference interface: what a headless caller needs
+    int LoadScene(const char* sce_path) {              // the `--input` file, Source/main.cpp:29-31
+        size_t n = 0;
+        if ((last_ = rm_load_sce(sce_path, nullptr, 0, &n)) != RM_OK) return last_;
+        std::vector<rm_node> nodes(n);
+        if ((last_ = rm_load_sce(sce_path, nodes.data(), n, &n)) != RM_OK) return last_;
+        SceneName = sce_path;
+        PrimitivesNum = n;
+        return last_ = rm_set_nodes(ctx_, nodes.data(), n);
+    }
+    int ReadPixels(std::vector<unsigned char>& rgba) {
+        rgba.resize(Width * Height * 4);
+        return last_ = rm_read_pixels(ctx_, rgba.data(), Width * 4);
+    }
+    float ProcessTime() const { return last_ms_; }
+    int LastStatus() const { return last_; }
+    rm_ctx* Context() { return ctx_; }
+};
+
+}  // namespace hip

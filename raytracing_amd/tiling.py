@@ -27,11 +27,31 @@ def max_local_rows(height, band_rows, nranks):
     return max(local_rows(height, band_rows, r, nranks) for r in range(nranks))
 
 
-def default_band_rows(height, nranks, target_bands_per_rank=8):
-    """Bands of a multiple of 16 rows, about `target_bands_per_rank` per rank, so
-    the costly middle of the image is dealt evenly."""
-    rows = height // max(1, nranks * target_bands_per_rank)
-    return max(16, (rows // 16) * 16)
+def default_band_rows(height, nranks):
+    """16 rows (one workgroup row): the finest deal, so the costly middle of the
+    image is spread evenly over the ranks."""
+    return 16
+
+
+def bands_per_rank(height, band_rows, nranks):
+    nbands = (height + band_rows - 1) // band_rows
+    return (nbands + nranks - 1) // nranks
+
+
+def padded_rows(height, band_rows, nranks):
+    """Rows of a frame buffer in which every rank owns the same number of whole
+    bands; the rows past `height` are never written by a kernel."""
+    return bands_per_rank(height, band_rows, nranks) * nranks * band_rows
+
+
+def assemble_into(frame_padded, parts, band_rows):
+    """One strided device copy: parts [nranks, bands_per_rank*band_rows, W, C]
+    (the gather's output on rank 0) -> frame_padded [padded_rows, W, C]."""
+    nranks, rows, width, ch = parts.shape
+    nb = rows // band_rows
+    dst = frame_padded.view(nb, nranks, band_rows, width, ch)
+    dst.copy_(parts.view(nranks, nb, band_rows, width, ch).permute(1, 0, 2, 3, 4))
+    return frame_padded
 
 
 def assemble(parts, height, band_rows):
