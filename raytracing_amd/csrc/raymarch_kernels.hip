@@ -30,7 +30,7 @@ namespace rm {
 
 struct P3 { float x, y, z; };
 
-// ---- scalar helpers (conventions of oracle/rm_oracle.h) ---------------------
+// ---- scalar helpers (same arithmetic conventions as the CPU restatement) ---------------------
 
 __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ float min2(float a, float b) { return (b < a) ? b : a; }   // std::min

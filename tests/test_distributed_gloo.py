@@ -1,0 +1,59 @@
+"""CPU suite, world_size 2 over gloo: the N>1 path of bench.py (row bands per rank,
+gather to rank 0, one strided interleave) with the CPU restatement standing in for
+the render kernel.  The assembled frame must equal the single-rank frame byte for byte."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, w, h, band, out_path):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    from oracle import oracle as O
+    from raytracing_amd import tiling
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nodes = O.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", "chair.sce"))
+    info = O.default_info(1, 0)
+    rows_max = tiling.bands_per_rank(h, band, world) * band
+    buf = torch.zeros((rows_max, w, 4), dtype=torch.uint8)
+    at = 0
+    for y0, y1 in tiling.band_of_rank(h, band, rank, world):          # what rm_set_bands + rm_process do on a GPU
+        part = O.render(nodes, w, h, info, rows=(y0, y1))["rgba"][y0:y1]
+        buf[at:at + (y1 - y0)] = torch.from_numpy(part)
+        at += y1 - y0
+    assert at == tiling.local_rows(h, band, rank, world)
+    parts = torch.zeros((world, rows_max, w, 4), dtype=torch.uint8) if rank == 0 else None
+    dist.gather(buf, list(parts.unbind(0)) if rank == 0 else None, dst=0)
+    if rank == 0:
+        frame = torch.zeros((tiling.padded_rows(h, band, world), w, 4), dtype=torch.uint8)
+        tiling.assemble_into(frame, parts, band)
+        np.save(out_path, frame[:h].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h,band", [(96, 70, 16), (64, 64, 32)])
+def test_two_rank_frame_equals_one_rank_frame(tmp_path, w, h, band):
+    from oracle import oracle as O
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(2, _free_port(), w, h, band, out), nprocs=2, join=True)
+    nodes = O.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", "chair.sce"))
+    want = O.render(nodes, w, h, O.default_info(1, 0))["rgba"]
+    assert np.array_equal(np.load(out), want)

@@ -1,0 +1,226 @@
+"""CPU suite: host logic of the product library (no GPU calls): C-ABI exports,
+bazo / .sce codecs in all three layouts, the scene flattener, error codes."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import kat_scenes
+from oracle import oracle as O
+from raytracing_amd import api, scenes, tiling
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/raymarching_amd.h declares is exported by the .so."""
+    with open(os.path.join(ROOT, "include", "raymarching_amd.h")) as f:
+        text = f.read()
+    import re
+    declared = sorted(set(re.findall(r"\b(rm_[a-z_0-9]+)\s*\(", text)))
+    assert declared, "no declarations parsed"
+    lib = api.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(api.EXPORTS) == declared
+
+
+def test_product_does_not_reach_the_oracle():
+    """The product tree never names the oracle, and the library does not link it."""
+    import re
+    uses = re.compile(r"import\s+oracle|from\s+oracle|from\s+\.+oracle|rm_oracle|rmo_|#\s*include[^\n]*oracle|-lrm_oracle")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "raytracing_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                with open(os.path.join(dirpath, fn), errors="ignore") as f:
+                    assert not uses.search(f.read()), os.path.join(dirpath, fn)
+    needed = subprocess.run(["readelf", "-d", api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rm_oracle" not in needed
+
+
+def test_decode_stock_scenes_matches_oracle(stock_scenes, golden_dir):
+    for name, want in stock_scenes.items():
+        got = api.load_sce(os.path.join(golden_dir, "scenes", name + ".sce"))
+        assert got.tobytes() == want.tobytes()
+
+
+def _record_llp64(node):
+    """a bazo record as the reference's current header lays it out with 4-byte counters"""
+    na = {0x100: 2, 0x101: 3, 0x102: 4, 0x103: 2, 0x104: 3, 0x105: 4, 0x107: 2, 0x108: 2}.get(int(node["type"]), None)
+    if na is None:
+        na = 0 if int(node["type"]) in (2, 3, 4, 0x80) else 1
+    body = b"".join(struct.pack("<i", int(v)) for v in node["o"][:na]) + node["f"].tobytes()
+    body = body[:24].ljust(24, b"\xcc")
+    return struct.pack("<I", int(node["type"])) + body + b"\x00" * 4 + b"\xee" * 16
+
+
+def _record_lp64(node):
+    na = {0x100: 2, 0x101: 3, 0x103: 2, 0x104: 3, 0x107: 2, 0x108: 2}.get(int(node["type"]), None)
+    if na is None:
+        na = 0 if int(node["type"]) in (2, 3, 4, 0x80) else 1
+    body = b"".join(struct.pack("<q", int(v)) for v in node["o"][:na]) + node["f"].tobytes()
+    body = body[:24].ljust(24, b"\xcc")
+    return struct.pack("<I", int(node["type"])) + body + b"\x00" * 4 + b"\xee" * 16
+
+
+def test_decode_all_layouts():
+    """LP64 / LLP64 in-memory records decode to the same nodes as the .sce form; the
+    garbage in unused payload bytes and in dist/norm is ignored."""
+    for name, table in kat_scenes.tables().items():
+        sce = O.encode_sce(table)
+        ref = api.decode_bazo(sce, api.BAZO_SCE)
+        llp = api.decode_bazo(b"".join(_record_llp64(n) for n in table), api.BAZO_LLP64)
+        assert llp.tobytes() == ref.tobytes(), name
+        if not any(int(t) in (0x102, 0x105) for t in table["type"]):
+            lp = api.decode_bazo(b"".join(_record_lp64(n) for n in table), api.BAZO_LP64)
+            assert lp.tobytes() == ref.tobytes(), name
+        assert O.decode_bazo(sce, O.BAZO_SCE).tobytes() == ref.tobytes()
+
+
+def test_lp64_rejects_four_way_combinators():
+    """kunigajo_4 needs 32 payload bytes with 8-byte counters: not representable (Include/objects_list.h:17)."""
+    rec = struct.pack("<I", 0x102) + b"\x00" * 44
+    with pytest.raises(api.RaymarchError) as e:
+        api.decode_bazo(rec, api.BAZO_LP64)
+    assert e.value.status == -3
+
+
+def test_sce_save_load_round_trip(tmp_path):
+    table = scenes.csg1024()
+    path = str(tmp_path / "csg.sce")
+    api.save_sce(path, table)
+    assert os.path.getsize(path) == 1024 * 48
+    assert api.load_sce(path).tobytes() == table.tobytes()
+    with open(path, "rb") as f:
+        assert f.read() == O.encode_sce(table)
+    with open(path, "ab") as f:
+        f.write(b"\x00" * 7)                               # not a whole number of records
+    with pytest.raises(api.RaymarchError) as e:
+        api.load_sce(path)
+    assert e.value.status == -4
+    with pytest.raises(api.RaymarchError):
+        api.load_sce(str(tmp_path / "missing.sce"))
+
+
+def test_csg1024_matches_committed_scene(golden_dir):
+    """config 4's generator is deterministic: it reproduces the committed .sce."""
+    table = scenes.csg1024()
+    assert len(table) == 1024 and int(table[1023]["type"]) == 0 and int(table[0]["type"]) == 0x200
+    kinds = [int(t) for t in table["type"]]
+    assert kinds.count(0x100) == 340 and kinds.count(0x200) == 342
+    assert kinds.count(0x2) + kinds.count(0x3) + kinds.count(0x4) == 341
+    with open(os.path.join(golden_dir, "scenes", "csg1024.sce"), "rb") as f:
+        assert f.read() == O.encode_sce(table)
+
+
+def test_flatten_stock_scenes(stock_scenes):
+    st, listing = api.flatten_scene(stock_scenes["chair"])
+    ops = [line.split()[1] for line in listing.strip().splitlines()]
+    assert ops == ["RIPETO", "MOVO", "ROTQ", "KUBO", "PUSHA_R", "SFERO", "SFERO", "NEG", "POPC_R", "END"]
+    assert st["reachable"] == 11 and st["value_slots"] == 0 and st["lds_bytes"] == 11 * 48
+    st, listing = api.flatten_scene(stock_scenes["infinity"])
+    assert [line.split()[1] for line in listing.strip().splitlines()] == ["RIPETO", "RIPETO", "RIPETO", "SFERO", "NEG", "END"]
+    # main.cpp's own list: komunajo_3 over a box and two complemented spheres -> one max chain
+    st, listing = api.flatten_scene(scenes.main_cpp_scene())
+    assert [line.split()[1] for line in listing.strip().splitlines()] == ["RIPETO", "MOVO", "ROTQ", "KUBO", "SFERO", "SFERO", "END"]
+    assert listing.count("neg comb=max") == 2
+
+
+def test_flatten_csg1024_is_one_running_min():
+    st, listing = api.flatten_scene(scenes.csg1024())
+    ops = [line.split()[1] for line in listing.strip().splitlines()]
+    assert ops[0] == "MOVO" and ops[-1] == "END" and len(ops) == 343
+    assert set(ops[1:-1]) <= {"SFERO", "KUBO", "CILINDRO"}
+    assert st["value_slots"] == 0 and st["reachable"] == 1023 and st["lds_bytes"] == 1024 * 48
+
+
+def test_flatten_stack_discipline():
+    """Every push has its pop, slots never overlap, frames restore before siblings."""
+    for name, table in kat_scenes.tables().items():
+        st, listing = api.flatten_scene(table)
+        live, b_live = {}, False
+        for line in listing.strip().splitlines():
+            f = line.split()
+            op = f[1]
+            slot = int([x for x in f if x.startswith("slot=")][0][5:])
+            if op == "PUSHA_R":
+                assert not b_live, name
+                b_live = True
+            elif op in ("POPC_R", "GLATA_R"):
+                assert b_live, name
+                b_live = False
+            elif op in ("PUSHA", "PORTANTA"):
+                assert slot not in live, name
+                live[slot] = 1
+            elif op in ("POPC", "GLATA", "PORTANTA_END"):
+                assert live.pop(slot) == 1, name
+            elif op == "PUSHF":
+                assert all(s not in live for s in (slot, slot + 1, slot + 2)), name
+                live[slot] = live[slot + 1] = live[slot + 2] = 3
+            elif op == "POPF":
+                assert live.pop(slot) == 3 and live.pop(slot + 1) == 3 and live.pop(slot + 2) == 3, name
+        assert not live and not b_live, name
+        assert st["value_slots"] <= 16
+
+
+def test_flatten_rejects_bad_tables(stock_scenes):
+    bad = stock_scenes["chair"].copy()
+    bad[8]["type"] = 0
+    with pytest.raises(api.RaymarchError) as e:
+        api.flatten_scene(bad)
+    assert e.value.status == -2
+    bad = stock_scenes["chair"].copy()
+    bad[6]["o"][1] = 40
+    with pytest.raises(api.RaymarchError) as e:
+        api.flatten_scene(bad)
+    assert e.value.status == -2
+    bad = stock_scenes["chair"].copy()
+    bad[0]["o"][0] = -1
+    with pytest.raises(api.RaymarchError) as e:
+        api.flatten_scene(bad)
+    assert e.value.status == -2
+    # a chain deeper than the walker's private stack
+    deep = scenes.Tree(_chain(80)).table()
+    with pytest.raises(api.RaymarchError) as e:
+        api.flatten_scene(deep)
+    assert e.value.status == -5
+    too_many = np.zeros(4096, dtype=api.NODE_DTYPE)
+    with pytest.raises(api.RaymarchError) as e:
+        api.flatten_scene(too_many)
+    assert e.value.status == -5
+
+
+def _chain(depth):
+    t = ("sfero", (1,))
+    for k in range(depth):
+        t = ("rotacioX", (1.0, 0.0), t)
+    return t
+
+
+def test_unreachable_nodes_are_ignored(stock_scenes):
+    """Records that nothing links to (the trailing nenio pad of config 4, odd-count over-read) do not matter."""
+    chair = stock_scenes["chair"]
+    padded = np.concatenate([chair, np.zeros(3, dtype=api.NODE_DTYPE)])
+    padded[12]["type"] = 0xDEAD
+    st, listing = api.flatten_scene(padded)
+    assert st["reachable"] == 11 and listing == api.flatten_scene(chair)[1]
+
+
+def test_tiling_partition_covers_every_row_once():
+    for (h, band, n) in [(2160, 16, 8), (4320, 16, 8), (250, 32, 3), (15, 16, 2), (1080, 16, 4), (480, 16, 1)]:
+        seen = np.zeros(h, dtype=int)
+        for r in range(n):
+            rows = tiling.band_of_rank(h, band, r, n)
+            assert sum(y1 - y0 for y0, y1 in rows) == tiling.local_rows(h, band, r, n)
+            assert tiling.local_rows(h, band, r, n) <= tiling.bands_per_rank(h, band, n) * band
+            for y0, y1 in rows:
+                seen[y0:y1] += 1
+        assert (seen == 1).all()
+        assert tiling.padded_rows(h, band, n) >= h and tiling.padded_rows(h, band, n) % (band * n) == 0
+
+
+def test_cpp_front_end_is_built():
+    assert os.path.exists(os.path.join(ROOT, "raytracing_amd", "rm_render")), "run __graft_entry__.build()"
