@@ -149,6 +149,11 @@ int rm_set_norm_batch(rm_ctx* ctx, int lanes);
  * (default), 1 = per-lane tree walker (diagnostic; identical results). */
 int rm_set_evaluator(rm_ctx* ctx, int which);
 
+/* Diagnostics: render one frame and return, per wavefront, 4 dwords: march
+ * loop trips, normal passes, shader cycles in the kernel, cycles in normal
+ * passes.  With host_out NULL only *n_waves is set. */
+int rm_debug_wave_stats(rm_ctx* ctx, uint32_t* host_out, size_t cap_waves, size_t* n_waves);
+
 const char* rm_status_string(int status);
 
 /* ---- node-level evaluation on the device (known-answer tests) ----------- */

@@ -28,7 +28,7 @@ EXPORTS = [
     "rm_local_rows", "rm_enable_hit_mask", "rm_process", "rm_process_async", "rm_synchronize",
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
-    "rm_eval_points", "rm_eval_rays",
+    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
             "rm_set_evaluator": [vp, i32],
             "rm_eval_points": [vp, i32, sz, vp, sz, vp, vp],
             "rm_eval_rays": [vp, vp, sz, vp],
+            "rm_debug_wave_stats": [vp, vp, sz, C.POINTER(sz)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -243,6 +244,14 @@ class Raymarching:
         p, pitch = C.c_void_p(), C.c_size_t(0)
         _check(lib().rm_device_framebuffer(self._ctx, C.byref(p), C.byref(pitch)), "rm_device_framebuffer")
         return p.value, pitch.value
+
+    def wave_stats(self):
+        """[waves, 4] uint32: loop trips, normal passes, cycles, cycles in normal passes."""
+        n = C.c_size_t(0)
+        _check(lib().rm_debug_wave_stats(self._ctx, None, 0, C.byref(n)), "rm_debug_wave_stats")
+        out = np.zeros((n.value, 4), dtype=np.uint32)
+        _check(lib().rm_debug_wave_stats(self._ctx, _ptr(out), n.value, C.byref(n)), "rm_debug_wave_stats")
+        return out
 
     # -- known-answer hooks
     def eval_points(self, pts, idx=0, which=1, want_norm=True):

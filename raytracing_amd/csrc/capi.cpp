@@ -317,6 +317,28 @@ int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char
     return RM_OK;
 }
 
+int rm_debug_wave_stats(rm_ctx* c, uint32_t* host_out, size_t cap_waves, size_t* n_waves) {
+    if (!c || !n_waves) return RM_ERR_INVALID_ARG;
+    if (!c->have_scene || !c->have_info) return RM_ERR_NOT_READY;
+    const size_t gx = (c->width + 15) / 16, gy = (c->local_rows + 15) / 16, waves = gx * gy * 4;
+    *n_waves = waves;
+    if (!host_out) return RM_OK;
+    if (cap_waves < waves) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc(&d, waves * 16));
+    rm::RenderParams p;
+    fill_params(c, p);
+    p.wave_stats = d;
+    hipError_t e = hipMemsetAsync(d, 0, waves * 16, c->stream);
+    if (e == hipSuccess) e = rm::launch_render(p, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), c->lds_bytes, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_out, d, waves * 16, hipMemcpyDeviceToHost, c->stream);
+    hipError_t s2 = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = s2;
+    (void)hipFree(d);
+    return static_cast<int>(e);
+}
+
 int rm_set_norm_batch(rm_ctx* c, int lanes) {
     if (!c || lanes < 1 || lanes > 64) return RM_ERR_INVALID_ARG;
     c->norm_batch = static_cast<uint32_t>(lanes);

@@ -32,6 +32,7 @@ struct RenderParams {
     uint32_t evaluator;           // 0 distance program, 1 tree walker
     uint8_t* rgba;  size_t pitch;
     uint8_t* hit;   size_t hit_pitch;
+    uint32_t* wave_stats;         // optional diagnostics, 4 dwords per wavefront
     Camera cam;
 };
 

@@ -98,99 +98,129 @@ __device__ __forceinline__ P3 ripeto(P3 p, float ax, float ay, float az, float a
 
 // =============================================================================
 // Wave-uniform distance program (scene_program.h).  Every lane of the wave must
-// call this together: `pc` and every slot word are wave-uniform, so slots are
-// fetched with scalar loads and operands stay in SGPRs.
+// call this together: `pc` and every slot word are wave-uniform.
+//
+// Fetch: one 32-byte slot = one s_load_dwordx8 into SGPRs, issued a whole slot
+// ahead of its use (the scalar data cache answers in ~250 cycles on gfx950; the
+// loads of a slot's operands must never sit on the dependent path).  The load is
+// written as inline asm because the compiler would split it and wait for the
+// opcode word first.  Operands are used straight from SGPRs by the VALU.
+//
+// Combine: the running value A starts at +inf (program start and after every
+// push), so "set" is "min" and both kinds are one v_med3_f32 with the third
+// operand -inf (min) or +inf (max).
+//
 // `stack` points at this lane's column of the workgroup's LDS stack; level k of
 // it lives at stack[k * RM_BLOCK_THREADS].
 // =============================================================================
-__device__ __forceinline__ float combine(uint32_t comb, float a, float v) {
-    return comb == COMB_MIN ? min2(a, v) : (comb == COMB_MAX ? max2(a, v) : v);
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ u32x8 fetch_slot(const Slot* prog, uint32_t byte_offset) {
+    u32x8 v;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(prog), "s"(byte_offset));
+    return v;
+}
+// the fetched registers may not be read (or copied) before this
+__device__ __forceinline__ void await_slot(u32x8& v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
+}
+
+struct Machine {
+    P3 F, P;          // frame point, work point
+    float A, B;       // running value, register copy of value slot 0
+    float tx, ty;     // rows x,y of a rotacioQ in flight
+};
+
+__device__ __forceinline__ float chain(float a, float v, float sel) { return __builtin_amdgcn_fmed3f(a, v, sel); }
+
+// Executes one slot.  Returns the number of slots to skip after it (portanta_sfero only).
+template <bool SRC_F>
+__device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* stack) {
+    const uint32_t w0 = w[0], op = w0 & 0xff, slot = w0 >> F_SLOT_SHIFT;
+    const P3 S = SRC_F ? m.F : m.P;
+    const float f1 = as_f(w[1]), f2 = as_f(w[2]), f3 = as_f(w[3]), f4 = as_f(w[4]),
+                f5 = as_f(w[5]), f6 = as_f(w[6]), f7 = as_f(w[7]);
+    // -inf continues a min chain, +inf a max chain
+    const float sel = as_f((w0 & (COMB_MAX << F_COMB_SHIFT)) ? 0x7f800000u : 0xff800000u);
+    const uint32_t sign = (w0 & F_NEG) ? 0x80000000u : 0u;
+    uint32_t skip = 0;
+    bool wrote_p = false;
+    switch (op) {
+    case OP_MOVO:    m.P = movo(S, f1, f2, f3); wrote_p = true; break;
+    case OP_ROTX:    m.P = rotx(S, f1, f2); wrote_p = true; break;
+    case OP_ROTY:    m.P = roty(S, f1, f2); wrote_p = true; break;
+    case OP_ROTZ:    m.P = rotz(S, f1, f2); wrote_p = true; break;
+    case OP_ROTQ_XY:          // rows x and y of P = p + 2*(Q p); the point itself is still needed for row z
+        m.tx = S.x + 2.f * (f1 * S.x + f2 * S.y + f3 * S.z);
+        m.ty = S.y + 2.f * (f4 * S.x + f5 * S.y + f6 * S.z);
+        break;
+    case OP_ROTQ_Z:
+        m.P = P3{m.tx, m.ty, S.z + 2.f * (f1 * S.x + f2 * S.y + f3 * S.z)};
+        wrote_p = true;
+        break;
+    case OP_RIPETO:  m.P = ripeto(S, f1, f2, f3, f4); wrote_p = true; break;
+    case OP_SETF:    m.F = m.P; break;
+    case OP_SFERO:   m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, sfero_dist(movo(S, f1, f2, f3), f4)) ^ sign), sel); break;
+    case OP_KUBO:    m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, kubo_dist(movo(S, f1, f2, f3), f4, f5, f6)) ^ sign), sel); break;
+    case OP_CILINDRO:m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, cilindro_dist(movo(S, f1, f2, f3), f4, f5)) ^ sign), sel); break;
+    case OP_EBENO:   m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, ebeno_dist(movo(S, f1, f2, f3), f4, f5, f6)) ^ sign), sel); break;
+    case OP_PUSHA_R: m.B = m.A; m.A = __builtin_inff(); break;
+    case OP_POPC_R:  m.A = chain(m.B, m.A, sel); break;
+    case OP_PUSHA:   stack[slot * RM_BLOCK_THREADS] = m.A; m.A = __builtin_inff(); break;
+    case OP_POPC:    m.A = chain(stack[slot * RM_BLOCK_THREADS], m.A, sel); break;
+    case OP_NEG:     m.A = -m.A; break;
+    case OP_GLATA_R: m.A = glata(m.B, m.A, f1, (w0 & F_NEG) != 0); break;
+    case OP_GLATA:   m.A = glata(stack[slot * RM_BLOCK_THREADS], m.A, f1, (w0 & F_NEG) != 0); break;
+    case OP_PUSHF:
+        stack[slot * RM_BLOCK_THREADS] = m.F.x;
+        stack[(slot + 1) * RM_BLOCK_THREADS] = m.F.y;
+        stack[(slot + 2) * RM_BLOCK_THREADS] = m.F.z;
+        m.F = m.P;
+        break;
+    case OP_POPF:
+        m.F.x = stack[slot * RM_BLOCK_THREADS];
+        m.F.y = stack[(slot + 1) * RM_BLOCK_THREADS];
+        m.F.z = stack[(slot + 2) * RM_BLOCK_THREADS];
+        break;
+    case OP_PORTANTA: {            // Source/cuda_kernels.cu:53-61
+        m.P = movo(S, f1, f2, f3);
+        float d = length_3(m.P.x, m.P.y, m.P.z) - f4;
+        stack[slot * RM_BLOCK_THREADS] = d;
+        // no lane inside the bounding sphere: the child's slots are dead for this wave
+        if (__builtin_amdgcn_ballot_w64(d <= RM_MIN_DIST) == 0) skip = w[5];
+        break;
+    }
+    case OP_PORTANTA_END: {
+        float d = stack[slot * RM_BLOCK_THREADS];
+        m.A = (d <= RM_MIN_DIST) ? m.A : d;
+        break;
+    }
+    default: break;
+    }
+    if (wrote_p && (w0 & F_DST_F)) m.F = m.P;
+    return skip;
 }
 
 __device__ __forceinline__ float run_program(const Slot* __restrict__ prog, P3 E, float* stack) {
-    P3 F = E, P = E;
-    float A = 0.f, B = 0.f;
+    Machine m;
+    m.F = E; m.P = E;
+    m.A = __builtin_inff(); m.B = 0.f; m.tx = 0.f; m.ty = 0.f;
     uint32_t pc = 0;
-    for (;;) {
-        const uint4* q = reinterpret_cast<const uint4*>(prog + pc);
-        const uint4 lo = q[0], hi = q[1];
-        const uint32_t w0 = __builtin_amdgcn_readfirstlane(lo.x);
-        const uint32_t op = w0 & 0xff;
-        if (op == OP_END) break;
-        ++pc;
-        const P3 S = (w0 & F_SRC_F) ? F : P;
-        const uint32_t comb = (w0 & F_COMB_MASK) >> F_COMB_SHIFT;
-        const uint32_t slot = w0 >> F_SLOT_SHIFT;
-        const float f1 = as_f(lo.y), f2 = as_f(lo.z), f3 = as_f(lo.w);
-        const float f4 = as_f(hi.x), f5 = as_f(hi.y), f6 = as_f(hi.z), f7 = as_f(hi.w);
-        switch (op) {
-        case OP_MOVO:   P = movo(S, f1, f2, f3); if (w0 & F_DST_F) F = P; break;
-        case OP_ROTX:   P = rotx(S, f1, f2);     if (w0 & F_DST_F) F = P; break;
-        case OP_ROTY:   P = roty(S, f1, f2);     if (w0 & F_DST_F) F = P; break;
-        case OP_ROTZ:   P = rotz(S, f1, f2);     if (w0 & F_DST_F) F = P; break;
-        case OP_ROTQ: {
-            const uint4 q2 = *reinterpret_cast<const uint4*>(prog + pc);
-            ++pc;
-            P = rotq(S, f1, f2, f3, f4, f5, f6, f7, as_f(q2.x), as_f(q2.y));
-            if (w0 & F_DST_F) F = P;
-            break;
+    u32x8 cur = fetch_slot(prog, 0);
+    await_slot(cur);
+    while ((cur[0] & 0xff) != OP_END) {
+        u32x8 nxt = fetch_slot(prog, (pc + 1) * (uint32_t)sizeof(Slot));      // in flight while `cur` executes
+        const uint32_t skip = (cur[0] & F_SRC_F) ? exec_slot<true>(m, cur, stack) : exec_slot<false>(m, cur, stack);
+        pc += 1;
+        if (skip) {                     // rare: the prefetched slot is not the next one
+            await_slot(nxt);
+            pc += skip;
+            nxt = fetch_slot(prog, pc * (uint32_t)sizeof(Slot));
         }
-        case OP_RIPETO: P = ripeto(S, f1, f2, f3, f4); if (w0 & F_DST_F) F = P; break;
-        case OP_SETF:   F = P; break;
-        case OP_SFERO: {
-            float v = sfero_dist(movo(S, f1, f2, f3), f4);
-            A = combine(comb, A, (w0 & F_NEG) ? -v : v);
-            break;
-        }
-        case OP_KUBO: {
-            float v = kubo_dist(movo(S, f1, f2, f3), f4, f5, f6);
-            A = combine(comb, A, (w0 & F_NEG) ? -v : v);
-            break;
-        }
-        case OP_CILINDRO: {
-            float v = cilindro_dist(movo(S, f1, f2, f3), f4, f5);
-            A = combine(comb, A, (w0 & F_NEG) ? -v : v);
-            break;
-        }
-        case OP_EBENO: {
-            float v = ebeno_dist(movo(S, f1, f2, f3), f4, f5, f6);
-            A = combine(comb, A, (w0 & F_NEG) ? -v : v);
-            break;
-        }
-        case OP_PUSHA_R: B = A; break;
-        case OP_POPC_R:  A = combine(comb, B, A); break;
-        case OP_PUSHA:   stack[slot * RM_BLOCK_THREADS] = A; break;
-        case OP_POPC:    A = combine(comb, stack[slot * RM_BLOCK_THREADS], A); break;
-        case OP_NEG:     A = -A; break;
-        case OP_GLATA_R: A = glata(B, A, f1, (w0 & F_NEG) != 0); break;
-        case OP_GLATA:   A = glata(stack[slot * RM_BLOCK_THREADS], A, f1, (w0 & F_NEG) != 0); break;
-        case OP_PUSHF:
-            stack[slot * RM_BLOCK_THREADS] = F.x;
-            stack[(slot + 1) * RM_BLOCK_THREADS] = F.y;
-            stack[(slot + 2) * RM_BLOCK_THREADS] = F.z;
-            F = P;
-            break;
-        case OP_POPF:
-            F.x = stack[slot * RM_BLOCK_THREADS];
-            F.y = stack[(slot + 1) * RM_BLOCK_THREADS];
-            F.z = stack[(slot + 2) * RM_BLOCK_THREADS];
-            break;
-        case OP_PORTANTA: {            // Source/cuda_kernels.cu:53-61
-            P = movo(S, f1, f2, f3);
-            float d = length_3(P.x, P.y, P.z) - f4;
-            stack[slot * RM_BLOCK_THREADS] = d;
-            if (__builtin_amdgcn_ballot_w64(d <= RM_MIN_DIST) == 0) pc += __builtin_amdgcn_readfirstlane(hi.y);
-            break;
-        }
-        case OP_PORTANTA_END: {
-            float d = stack[slot * RM_BLOCK_THREADS];
-            A = (d <= RM_MIN_DIST) ? A : d;
-            break;
-        }
-        default: break;
-        }
+        await_slot(nxt);
+        cur = nxt;
     }
-    return A;
+    return m.A;
 }
 
 // =============================================================================
@@ -494,10 +524,15 @@ render_kernel(const RenderParams prm) {
         else shadow_tail();
     };
 
+    // optional per-wave diagnostics (rm_debug_wave_stats): trips, normal passes, cycles
+    uint32_t st_evals = 0, st_norms = 0, st_norm_cycles = 0;
+    const uint64_t st_t0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
+
     for (;;) {
         const bool active = (mode != M_DONE) && !need;
         const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
         if (amask != 0) {
+            ++st_evals;
             // DIST(root, pos) for the whole wave (:627 and :661 share this)
             float d = (prm.evaluator == 0) ? run_program(prm.program, pos, stack)
                                            : walk_dist(tree, 0, pos, st, 0);
@@ -524,6 +559,8 @@ render_kernel(const RenderParams prm) {
         const unsigned long long run = __builtin_amdgcn_ballot_w64((mode != M_DONE) && !need);
         if (nmask == 0) { if (run == 0) break; continue; }
         if (run != 0 && (uint32_t)__builtin_popcountll(nmask) < prm.norm_batch) continue;
+        const uint64_t st_n0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
+        ++st_norms;
         if (need) {                                                            // :635-637, :668-670
             P3 N = walk_norm(tree, 0, pos, st);
             float R_1 = r_length_3(N.x, N.y, N.z);
@@ -531,6 +568,12 @@ render_kernel(const RenderParams prm) {
             if (mode == M_PRIMARY) primary_normal(n); else shadow_normal(n);
             need = false;
         }
+        if (prm.wave_stats) st_norm_cycles += (uint32_t)(__builtin_amdgcn_s_memtime() - st_n0);
+    }
+
+    if (prm.wave_stats && lane == 0) {
+        uint32_t* o = prm.wave_stats + 4 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
+        o[0] = st_evals; o[1] = st_norms; o[2] = (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0); o[3] = st_norm_cycles;
     }
 
     if (in_image) {                                                            // :717

@@ -233,7 +233,7 @@ struct Flattener {
     void eval(size_t idx, Src src) {
         if (err) return;
         if (!check_chain(idx)) return;
-        if (try_prim(idx, src, COMB_SET)) return;
+        if (try_prim(idx, src, COMB_MIN)) return;    // the running value is +inf here: min == set
         if (!descend(idx)) return;
         const rm_node& nd = nodes[idx];
         const uint32_t sflag = (src == SRC_F ? F_SRC_F : 0);
@@ -260,12 +260,12 @@ struct Flattener {
         case RM_TYPE_ROTACIOQ: {
             float Q[9];
             build_q(nd, Q);
-            emit(OP_ROTQ, sflag);
+            emit(OP_ROTQ_XY, sflag);
             size_t at = prog.size() - 1;
-            emit(OP_END);                      // operand slot, never dispatched
-            for (int k = 0; k < 7; ++k) prog[at].w[1 + k] = fbits(Q[k]);
-            prog[at + 1].w[0] = fbits(Q[7]); prog[at + 1].w[1] = fbits(Q[8]);
-            last_xf = static_cast<long>(at);
+            for (int k = 0; k < 6; ++k) prog[at].w[1 + k] = fbits(Q[k]);
+            emit(OP_ROTQ_Z, sflag);
+            for (int k = 0; k < 3; ++k) prog[at + 1].w[1 + k] = fbits(Q[6 + k]);
+            last_xf = static_cast<long>(at + 1);
             eval(child(idx, 0), SRC_P);
             break;
         }
@@ -410,6 +410,7 @@ int build_scene(const rm_node* nodes, size_t n, SceneBuild& out) {
     fl.eval(0, SRC_F);
     if (fl.err) return fl.err;
     fl.emit(OP_END);
+    fl.emit(OP_END);      // the interpreter fetches one slot past the one it executes
     if (fl.err) return fl.err;
     out.program.swap(fl.prog);
     out.value_slots = fl.max_sp;
@@ -423,11 +424,11 @@ int build_scene(const rm_node* nodes, size_t n, SceneBuild& out) {
 
 std::string disassemble(const std::vector<Slot>& program) {
     static const char* names[OP_COUNT] = {
-        "END", "MOVO", "ROTX", "ROTY", "ROTZ", "ROTQ", "RIPETO", "SETF",
+        "END", "MOVO", "ROTX", "ROTY", "ROTZ", "ROTQ_XY", "ROTQ_Z", "RIPETO", "SETF",
         "SFERO", "KUBO", "CILINDRO", "EBENO",
         "PUSHA_R", "POPC_R", "PUSHA", "POPC", "NEG", "GLATA_R", "GLATA",
         "PUSHF", "POPF", "PORTANTA", "PORTANTA_END" };
-    static const char* combs[4] = { "set", "min", "max", "?" };
+    static const char* combs[4] = { "-", "min", "max", "?" };
     std::string s;
     char line[256];
     for (size_t pc = 0; pc < program.size(); ++pc) {
@@ -441,7 +442,6 @@ std::string disassemble(const std::vector<Slot>& program) {
                       f[0], f[1], f[2], f[3], f[4], f[5], f[6]);
         s += line;
         if (op == OP_END) break;
-        if (op == OP_ROTQ) ++pc;
     }
     return s;
 }

@@ -55,7 +55,8 @@ static_assert(sizeof(TreeNode) == 48, "tree node is 48 bytes");
 // stack depth at every instruction is static).
 //
 // Slot word 0:  bits 0-7 opcode | bit 8 SRC_F | bit 9 DST_F | bit 10 NEG |
-//               bits 11-12 combine (0 set, 1 min, 2 max) | bits 16-31 stack slot
+//               bits 11-12 combine (1 min, 2 max; the running value starts at +inf,
+//               so a first value is a min too) | bits 16-31 stack slot
 enum Op : uint32_t {
     OP_END = 0,
     // transforms: dst = T(src).  w1.. operands
@@ -63,7 +64,8 @@ enum Op : uint32_t {
     OP_ROTX,      // w1 cos, w2 sin
     OP_ROTY,
     OP_ROTZ,
-    OP_ROTQ,      // two slots: w1-7 = xx xy xz yx yy yz zx ; next slot w0-1 = zy zz
+    OP_ROTQ_XY,   // rows x,y of P = p + 2 (Q p) into temporaries: w1-6 = xx xy xz yx yy yz
+    OP_ROTQ_Z,    // row z, then P = (tx, ty, z): w1-3 = zx zy zz   (always follows OP_ROTQ_XY, same src)
     OP_RIPETO,    // w1-3 a, w4 dot(a,a)
     OP_SETF,      // F = P
     // primitives: v = prim(src - t) ; v = NEG ? -v : v ; A = combine(A, v)
@@ -72,9 +74,9 @@ enum Op : uint32_t {
     OP_CILINDRO,  // w1-3 t, w4 r, w5 h
     OP_EBENO,     // w1-3 t, w4-6 n
     // value stack
-    OP_PUSHA_R,   // B = A
+    OP_PUSHA_R,   // B = A ; A = +inf
     OP_POPC_R,    // A = combine(B, A)
-    OP_PUSHA,     // stack[slot] = A
+    OP_PUSHA,     // stack[slot] = A ; A = +inf
     OP_POPC,      // A = combine(stack[slot], A)
     OP_NEG,       // A = -A
     OP_GLATA_R,   // A = smooth(B, A, k)            w1 k, NEG bit: 0 kunigajo, 1 komunajo

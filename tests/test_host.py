@@ -119,13 +119,13 @@ def test_csg1024_matches_committed_scene(golden_dir):
 def test_flatten_stock_scenes(stock_scenes):
     st, listing = api.flatten_scene(stock_scenes["chair"])
     ops = [line.split()[1] for line in listing.strip().splitlines()]
-    assert ops == ["RIPETO", "MOVO", "ROTQ", "KUBO", "PUSHA_R", "SFERO", "SFERO", "NEG", "POPC_R", "END"]
+    assert ops == ["RIPETO", "MOVO", "ROTQ_XY", "ROTQ_Z", "KUBO", "PUSHA_R", "SFERO", "SFERO", "NEG", "POPC_R", "END"]
     assert st["reachable"] == 11 and st["value_slots"] == 0 and st["lds_bytes"] == 11 * 48
     st, listing = api.flatten_scene(stock_scenes["infinity"])
     assert [line.split()[1] for line in listing.strip().splitlines()] == ["RIPETO", "RIPETO", "RIPETO", "SFERO", "NEG", "END"]
     # main.cpp's own list: komunajo_3 over a box and two complemented spheres -> one max chain
     st, listing = api.flatten_scene(scenes.main_cpp_scene())
-    assert [line.split()[1] for line in listing.strip().splitlines()] == ["RIPETO", "MOVO", "ROTQ", "KUBO", "SFERO", "SFERO", "END"]
+    assert [line.split()[1] for line in listing.strip().splitlines()] == ["RIPETO", "MOVO", "ROTQ_XY", "ROTQ_Z", "KUBO", "SFERO", "SFERO", "END"]
     assert listing.count("neg comb=max") == 2
 
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Times the render kernel over a few workloads and knob settings (GPU box)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O          # camera block only
+from raytracing_amd import api
+
+
+def time_it(nodes, w, h, info, reps=5, **knobs):
+    with api.Raymarching(w, h) as rm:
+        rm.set_nodes(nodes)
+        rm.set_info(info)
+        if "evaluator" in knobs:
+            rm.set_evaluator(knobs["evaluator"])
+        if "norm_batch" in knobs:
+            rm.set_norm_batch(knobs["norm_batch"])
+        rm.process()
+        ms = sorted(rm.process() for _ in range(reps))
+        return ms[len(ms) // 2]
+
+
+def main():
+    info = O.default_info(1, 0)
+    G = os.path.join(ROOT, "tests", "golden", "scenes")
+    scenes = {n: api.load_sce(os.path.join(G, n + ".sce")) for n in ("chair", "infinity", "csg1024")}
+    jobs = [("chair", 3840, 2160), ("chair", 1920, 1080), ("chair", 640, 480), ("infinity", 3840, 2160), ("csg1024", 960, 540)]
+    only = sys.argv[1:] 
+    for name, w, h in jobs:
+        if only and name not in only:
+            continue
+        base = time_it(scenes[name], w, h, info)
+        line = "%-9s %4dx%-4d  program %8.3f ms  %8.1f Mrays/s" % (name, w, h, base, w * h / base / 1e3)
+        for nb in (1, 4, 32, 64):
+            line += "  nb%d %.3f" % (nb, time_it(scenes[name], w, h, info, norm_batch=nb))
+        line += "  walker %.3f" % time_it(scenes[name], w, h, info, reps=3, evaluator=1)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
