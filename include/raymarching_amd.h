@@ -37,7 +37,8 @@ enum rm_status {
     RM_ERR_IO          = -4,  /* file could not be read / written / wrong size       */
     RM_ERR_TOO_LARGE   = -5,  /* scene exceeds RM_MAX_NODES or the LDS budget        */
     RM_ERR_NOT_READY   = -6,  /* rm_process before primitives and info were set      */
-    RM_ERR_NO_KERNEL   = -7   /* the HIP code object for gfx950 could not be loaded  */
+    RM_ERR_NO_KERNEL   = -7,  /* the HIP code object for gfx950 could not be loaded  */
+    RM_ERR_JIT         = -8   /* run-time compilation of the scene failed            */
 };
 
 #define RM_MAX_NODES 2048     /* reference: 256 (Source/cuda_kernels.cu:607) */
@@ -132,6 +133,7 @@ typedef struct rm_scene_stats {
     uint32_t lds_bytes;        /* dynamic LDS per 256-thread workgroup         */
     uint32_t kernel_vgprs;     /* register footprint reported by the runtime   */
     uint32_t kernel_scratch;   /* private (scratch) bytes per lane             */
+    uint32_t jit;              /* 1: the scene runs on per-scene generated code */
 } rm_scene_stats;
 int rm_get_scene_stats(rm_ctx* ctx, rm_scene_stats* out);
 
@@ -139,6 +141,22 @@ int rm_get_scene_stats(rm_ctx* ctx, rm_scene_stats* out);
  * stats (optional) receives the host-side fields; listing (optional) receives a
  * NUL-terminated text listing of the distance program, truncated to cap. */
 int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char* listing, size_t cap);
+
+/* Per-scene code generation (the counterpart of the reference's NVRTC step,
+ * Source/cuda_rays.cu:59-153: there the fixed kernel source is compiled at
+ * start-up; here the SCENE is compiled, each node becoming straight-line code).
+ * mode 0: never, every scene runs on the generic distance program;
+ * mode 1 (default): scenes of up to 64 reachable nodes are compiled with hiprtc
+ *         when rm_set_primitives / rm_set_nodes is called, falling back to the
+ *         generic program if compilation fails (rm_get_scene_stats().jit tells);
+ * mode 2: as 1, but a scene that cannot be compiled is an error.
+ * Takes effect at the next scene upload.  Environment RM_JIT=<mode> sets the
+ * default; RM_JIT_CACHE=<dir> keeps code objects on disk between processes. */
+int rm_set_jit(rm_ctx* ctx, int mode);
+int rm_jit_log(rm_ctx* ctx, char* buf, size_t cap);
+/* Host-only: generate and compile the code of a scene for `arch` without a
+ * device.  text receives the generated source (want_source != 0) or the log. */
+int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_source, char* text, size_t cap);
 
 /* Tuning: how many of a wavefront's lanes must be waiting for a surface normal
  * before the wave leaves the march loop to compute them (1..64).  Results do
@@ -160,7 +178,8 @@ const char* rm_status_string(int status);
 
 /* Evaluate DIST/NORM of node `idx` of the context's scene at `count` points
  * (host arrays of xyz triples) with the device evaluators.  which: 0 = program
- * (idx must be 0), 1 = tree walker.  norm_out may be NULL. */
+ * (idx must be 0), 1 = tree walker, 2 = generated code (idx must be 0).
+ * norm_out may be NULL. */
 int rm_eval_points(rm_ctx* ctx, int which, size_t idx, const float* xyz, size_t count,
                    float* dist_out, float* norm_out);
 

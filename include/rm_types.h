@@ -14,8 +14,16 @@
 #ifndef RM_TYPES_H
 #define RM_TYPES_H
 
+#ifdef __HIPCC_RTC__      /* run-time compilation: no system headers */
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+#else
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {

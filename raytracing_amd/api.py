@@ -28,13 +28,13 @@ EXPORTS = [
     "rm_local_rows", "rm_enable_hit_mask", "rm_process", "rm_process_async", "rm_synchronize",
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
-    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats",
+    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_jit", "rm_jit_log", "rm_jit_check",
 ]
 
 
 class SceneStats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("nodes", "reachable", "program_slots", "value_slots",
-                                          "tree_depth", "lds_bytes", "kernel_vgprs", "kernel_scratch")]
+                                          "tree_depth", "lds_bytes", "kernel_vgprs", "kernel_scratch", "jit")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -93,6 +93,9 @@ def lib():
             "rm_eval_points": [vp, i32, sz, vp, sz, vp, vp],
             "rm_eval_rays": [vp, vp, sz, vp],
             "rm_debug_wave_stats": [vp, vp, sz, C.POINTER(sz)],
+            "rm_set_jit": [vp, i32],
+            "rm_jit_log": [vp, C.c_char_p, sz],
+            "rm_jit_check": [vp, sz, C.c_char_p, i32, C.c_char_p, sz],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -146,6 +149,14 @@ def flatten_scene(nodes, listing_cap=1 << 20):
     buf = C.create_string_buffer(listing_cap)
     _check(lib().rm_flatten_scene(_ptr(nodes), nodes.size, C.byref(st), buf, listing_cap), "rm_flatten_scene")
     return st.as_dict(), buf.value.decode()
+
+
+def jit_check(nodes, arch="gfx950", want_source=False, cap=1 << 20):
+    """Host-only: generate + compile a scene's code with hiprtc.  Returns (status, source or log)."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    buf = C.create_string_buffer(cap)
+    rc = lib().rm_jit_check(_ptr(nodes), nodes.size, arch.encode(), 1 if want_source else 0, buf, cap)
+    return rc, buf.value.decode(errors="replace")
 
 
 class Raymarching:
@@ -203,6 +214,14 @@ class Raymarching:
 
     def enable_hit_mask(self, enable=True):
         _check(lib().rm_enable_hit_mask(self._ctx, 1 if enable else 0), "rm_enable_hit_mask")
+
+    def set_jit(self, mode):
+        _check(lib().rm_set_jit(self._ctx, mode), "rm_set_jit")
+
+    def jit_log(self):
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().rm_jit_log(self._ctx, buf, 1 << 16), "rm_jit_log")
+        return buf.value.decode(errors="replace")
 
     def set_norm_batch(self, lanes):
         _check(lib().rm_set_norm_batch(self._ctx, lanes), "rm_set_norm_batch")

@@ -10,6 +10,9 @@
 #include <vector>
 
 #include "../../include/raymarching_amd.h"
+#include <cstdlib>
+
+#include "jit.h"
 #include "kernel_params.h"
 #include "scene_build.h"
 
@@ -37,7 +40,12 @@ struct rm_ctx {
     size_t local_rows = 0;
     uint32_t norm_batch = 16, evaluator = 0;
     size_t lds_bytes = 0;
-    int vgprs = 0, scratch = 0;
+    int vgprs = 0, scratch = 0;       // of the ahead-of-time (interpreter) kernel
+
+    int jit_mode = 1;                 // 0 never, 1 when the scene is small enough, 2 required
+    bool jit_active = false;          // the current scene runs on generated code
+    rm::JitKernels jit;
+    std::string jit_log;
 };
 
 namespace {
@@ -91,6 +99,23 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { (void)hipFree(d_prog); (void)hipFree(d_tree); return static_cast<int>(e); }
 
+    // per-scene generated code (jit.h); the generic program and tree stay uploaded
+    // either way: known-answer hooks and rm_set_evaluator use them
+    bool jit_ok = false;
+    rm::JitKernels jit;
+    c->jit_log.clear();
+    if (c->jit_mode != 0 && built.reachable <= rm::kJitMaxNodes) {
+        const std::string src = rm::generate_scene_source(nodes, n, built.seen.data());
+        hipError_t je = rm::jit_compile(c->device, src, &jit, &c->jit_log);
+        jit_ok = je == hipSuccess;
+        if (!jit_ok && c->jit_mode == 2) { (void)hipFree(d_prog); (void)hipFree(d_tree); return RM_ERR_JIT; }
+    } else if (c->jit_mode == 2) {
+        (void)hipFree(d_prog); (void)hipFree(d_tree);
+        return RM_ERR_TOO_LARGE;
+    }
+    c->jit_active = jit_ok;
+    c->jit = jit;
+
     if (c->d_program) (void)hipFree(c->d_program);
     if (c->d_tree) (void)hipFree(c->d_tree);
     c->d_program = d_prog; c->d_tree = d_tree;
@@ -128,6 +153,7 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     rm_ctx* c = new (std::nothrow) rm_ctx;
     if (!c) return static_cast<int>(hipErrorOutOfMemory);
     c->device = device; c->width = width; c->height = height;
+    if (const char* env = std::getenv("RM_JIT")) c->jit_mode = std::atoi(env) < 0 ? 0 : std::atoi(env) > 2 ? 2 : std::atoi(env);
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -230,6 +256,7 @@ int rm_process_async(rm_ctx* c) {
     rm::RenderParams p;
     fill_params(c, p);
     dim3 grid(static_cast<unsigned>((c->width + 15) / 16), static_cast<unsigned>((c->local_rows + 15) / 16));
+    if (c->jit_active && c->evaluator == 0) return static_cast<int>(rm::jit_launch_render(c->jit, p, grid, c->stream));
     return static_cast<int>(rm::launch_render(p, grid, c->lds_bytes, c->stream));
 }
 
@@ -289,8 +316,9 @@ int rm_get_scene_stats(rm_ctx* c, rm_scene_stats* out) {
     out->value_slots = c->scene.value_slots;
     out->tree_depth = c->scene.tree_depth;
     out->lds_bytes = static_cast<uint32_t>(c->lds_bytes);
-    out->kernel_vgprs = static_cast<uint32_t>(c->vgprs);
-    out->kernel_scratch = static_cast<uint32_t>(c->scratch);
+    out->kernel_vgprs = static_cast<uint32_t>(c->jit_active ? c->jit.vgprs : c->vgprs);
+    out->kernel_scratch = static_cast<uint32_t>(c->jit_active ? c->jit.scratch : c->scratch);
+    out->jit = c->jit_active ? 1u : 0u;
     return RM_OK;
 }
 
@@ -331,12 +359,47 @@ int rm_debug_wave_stats(rm_ctx* c, uint32_t* host_out, size_t cap_waves, size_t*
     fill_params(c, p);
     p.wave_stats = d;
     hipError_t e = hipMemsetAsync(d, 0, waves * 16, c->stream);
-    if (e == hipSuccess) e = rm::launch_render(p, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), c->lds_bytes, c->stream);
+    if (e == hipSuccess)
+        e = (c->jit_active && c->evaluator == 0)
+                ? rm::jit_launch_render(c->jit, p, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), c->stream)
+                : rm::launch_render(p, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), c->lds_bytes, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(host_out, d, waves * 16, hipMemcpyDeviceToHost, c->stream);
     hipError_t s2 = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = s2;
     (void)hipFree(d);
     return static_cast<int>(e);
+}
+
+int rm_set_jit(rm_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return RM_ERR_INVALID_ARG;
+    c->jit_mode = mode;
+    return RM_OK;
+}
+
+int rm_jit_log(rm_ctx* c, char* buf, size_t cap) {
+    if (!c || !buf || !cap) return RM_ERR_INVALID_ARG;
+    size_t k = c->jit_log.size() < cap - 1 ? c->jit_log.size() : cap - 1;
+    std::memcpy(buf, c->jit_log.data(), k);
+    buf[k] = 0;
+    return RM_OK;
+}
+
+int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_source, char* text, size_t cap) {
+    rm::SceneBuild built;
+    int rc = rm::build_scene(nodes, n, built);
+    if (rc != RM_OK) return rc;
+    if (built.reachable > rm::kJitMaxNodes) return RM_ERR_TOO_LARGE;
+    const std::string scene = rm::generate_scene_source(nodes, n, built.seen.data());
+    std::string log;
+    std::vector<char> code;
+    const bool ok = rm::jit_build_code(arch ? arch : "gfx950", rm::jit_full_source(scene), &code, &log);
+    if (text && cap) {
+        const std::string& src = want_source ? scene : log;
+        size_t k = src.size() < cap - 1 ? src.size() : cap - 1;
+        std::memcpy(text, src.data(), k);
+        text[k] = 0;
+    }
+    return ok ? RM_OK : RM_ERR_JIT;
 }
 
 int rm_set_norm_batch(rm_ctx* c, int lanes) {
@@ -361,14 +424,16 @@ const char* rm_status_string(int status) {
     case RM_ERR_TOO_LARGE: return "scene too large (nodes, tree depth, program slots or LDS)";
     case RM_ERR_NOT_READY: return "primitives and rays_info must be set first";
     case RM_ERR_NO_KERNEL: return "no gfx950 code object for this device";
+    case RM_ERR_JIT: return "run-time compilation of the scene failed (see rm_jit_log)";
     default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
     }
 }
 
 int rm_eval_points(rm_ctx* c, int which, size_t idx, const float* xyz, size_t count, float* dist_out, float* norm_out) {
-    if (!c || !xyz || !dist_out || count == 0 || count > (1u << 24) || (which != 0 && which != 1)) return RM_ERR_INVALID_ARG;
+    if (!c || !xyz || !dist_out || count == 0 || count > (1u << 24) || which < 0 || which > 2) return RM_ERR_INVALID_ARG;
     if (!c->have_scene) return RM_ERR_NOT_READY;
-    if (idx >= c->n_nodes || (which == 0 && idx != 0)) return RM_ERR_INVALID_ARG;
+    if (idx >= c->n_nodes || (which != 1 && idx != 0)) return RM_ERR_INVALID_ARG;
+    if (which == 2 && !c->jit_active) return RM_ERR_NOT_READY;
     if (!c->scene.seen[idx]) return RM_ERR_INVALID_ARG;   // not reachable from node 0: never flattened
     HIP_TRY(hipSetDevice(c->device));
     float *d_xyz = nullptr, *d_dist = nullptr, *d_norm = nullptr;
@@ -379,8 +444,11 @@ int rm_eval_points(rm_ctx* c, int which, size_t idx, const float* xyz, size_t co
     if (e == hipSuccess) {
         rm::RenderParams p;
         fill_params(c, p);
-        e = rm::launch_eval_points(p, which, static_cast<uint32_t>(idx), d_xyz, static_cast<uint32_t>(count),
-                                   d_dist, d_norm, c->lds_bytes, c->stream);
+        if (which == 2)
+            e = rm::jit_launch_eval_points(c->jit, p, d_xyz, static_cast<uint32_t>(count), d_dist, d_norm, c->stream);
+        else
+            e = rm::launch_eval_points(p, which, static_cast<uint32_t>(idx), d_xyz, static_cast<uint32_t>(count),
+                                       d_dist, d_norm, c->lds_bytes, c->stream);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(dist_out, d_dist, count * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && norm_out) e = hipMemcpyAsync(norm_out, d_norm, count * 12, hipMemcpyDeviceToHost, c->stream);

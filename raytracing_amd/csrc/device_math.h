@@ -1,0 +1,139 @@
+// device_math.h - point type, scalar conventions, primitives, transforms, leaf
+// normals, ray generation: everything both the interpreter build and the
+// per-scene generated code share.  Compiles under hipcc and under hiprtc.
+#pragma once
+#include "../../include/rm_types.h"
+#include "kernel_params.h"
+
+namespace rm {
+
+struct P3 { float x, y, z; };
+
+// ---- scalar helpers (same arithmetic conventions as the CPU restatement) ---------------------
+
+__device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ float min2(float a, float b) { return (b < a) ? b : a; }   // std::min
+__device__ __forceinline__ float max2(float a, float b) { return (a < b) ? b : a; }   // std::max
+// Include/cuda_defines.cuh:49-53
+__device__ __forceinline__ float length_3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+__device__ __forceinline__ float r_length_3(float x, float y, float z) { return 1.f / sqrtf(x * x + y * y + z * z); }
+__device__ __forceinline__ float length_2(float x, float y) {
+    return (float)sqrt((double)x * (double)x + (double)y * (double)y);
+}
+// Source/cuda_kernels.cu:38-44
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax * bx + ay * by + az * bz;
+}
+__device__ __forceinline__ float mixf(float a, float b, float x) { return a + x * (b - a); }
+
+// ---- primitives (Source/cuda_kernels.cu:72-136), q = query point -------------
+
+__device__ __forceinline__ float sfero_dist(P3 q, float r) { return length_3(q.x, q.y, q.z) - r; }
+
+__device__ __forceinline__ float kubo_dist(P3 p, float bx, float by, float bz) {
+    float qx = fabsf(p.x) - bx, qy = fabsf(p.y) - by, qz = fabsf(p.z) - bz;
+    float inside = max2(qx, max2(qy, qz));
+    float outside = length_3(max2(qx, 0.f), max2(qy, 0.f), max2(qz, 0.f));
+    return (qx < 0.f && qy < 0.f && qz < 0.f) ? inside : outside;
+}
+
+__device__ __forceinline__ float cilindro_dist(P3 p, float r, float h) {
+    float qx = length_2(p.x, p.y) - r, qy = fabsf(p.z) - h;
+    float inside = qx > qy ? qx : qy;
+    float outside = length_2(max2(qx, 0.f), max2(qy, 0.f));
+    return (qx < 0.f && qy < 0.f) ? inside : outside;
+}
+
+__device__ __forceinline__ float ebeno_dist(P3 p, float nx, float ny, float nz) {
+    return dot3(nx, ny, nz, p.x, p.y, p.z);
+}
+
+// smooth union / intersection (Source/cuda_kernels.cu:356-359, :384-387)
+__device__ __forceinline__ float glata(float d0, float d1, float k, bool komunajo) {
+    float q = (d0 - d1) / k;
+    float h = (komunajo ? (1.f + q) : (1.f - q)) * .5f;
+    float m = mixf(d0, d1, h);
+    float e = k * h * (1.f - h);
+    float blended = komunajo ? (m + e) : (m - e);
+    return h > 1.f ? d0 : (h < 0.f ? d1 : blended);
+}
+
+// ---- transforms (Source/cuda_kernels.cu:409-413,430-432,454-456,478-480,527-530,577-581)
+
+__device__ __forceinline__ P3 movo(P3 p, float tx, float ty, float tz) { return P3{p.x - tx, p.y - ty, p.z - tz}; }
+__device__ __forceinline__ P3 rotx(P3 p, float c, float s) { return P3{p.x, c * p.y + s * p.z, -s * p.y + c * p.z}; }
+__device__ __forceinline__ P3 roty(P3 p, float c, float s) { return P3{-s * p.z + c * p.x, p.y, c * p.z + s * p.x}; }
+__device__ __forceinline__ P3 rotz(P3 p, float c, float s) { return P3{c * p.x + s * p.y, -s * p.x + c * p.y, p.z}; }
+__device__ __forceinline__ P3 rotq(P3 p, float xx, float xy, float xz, float yx, float yy, float yz,
+                                   float zx, float zy, float zz) {
+    return P3{p.x + 2.f * (xx * p.x + xy * p.y + xz * p.z),
+              p.y + 2.f * (yx * p.x + yy * p.y + yz * p.z),
+              p.z + 2.f * (zx * p.x + zy * p.y + zz * p.z)};
+}
+__device__ __forceinline__ P3 ripeto(P3 p, float ax, float ay, float az, float aa) {
+    float N = floorf(dot3(ax, ay, az, p.x, p.y, p.z) / aa + .5f);
+    return P3{p.x - N * ax, p.y - N * ay, p.z - N * az};
+}
+
+// ---- leaf normals (Source/cuda_kernels.cu:94-104, :120-126), unnormalised ----
+
+__device__ __forceinline__ P3 kubo_norm(P3 p, float bx, float by, float bz) {
+    float qx = fabsf(p.x) - bx, qy = fabsf(p.y) - by, qz = fabsf(p.z) - bz;
+    float sx = p.x > 0.f ? 1.f : -1.f, sy = p.y > 0.f ? 1.f : -1.f, sz = p.z > 0.f ? 1.f : -1.f;
+    if (qx < 0.f && qy < 0.f && qz < 0.f) {
+        if (qx > qz) return (qx > qy) ? P3{sx, 0.f, 0.f} : P3{0.f, sy, 0.f};
+        return (qy > qz) ? P3{0.f, sy, 0.f} : P3{0.f, 0.f, sz};
+    }
+    return P3{qx > 0.f ? sx : 0.f, qy > 0.f ? sy : 0.f, qz > 0.f ? sz : 0.f};
+}
+
+__device__ __forceinline__ P3 cilindro_norm(P3 p, float r, float h) {
+    float qx = length_2(p.x, p.y) - r, qy = fabsf(p.z) - h;
+    return (qx > qy) ? P3{p.x, p.y, 0.f} : P3{0.f, 0.f, p.z > 0.f ? 1.f : -1.f};
+}
+
+// ---- normals carried back through rotations (:443-445, :467-469, :491-493, :566-569)
+
+__device__ __forceinline__ P3 rotx_back(P3 n, float c, float s) { return P3{n.x, c * n.y - s * n.z, s * n.y + c * n.z}; }
+__device__ __forceinline__ P3 roty_back(P3 n, float c, float s) { return P3{s * n.z + c * n.x, n.y, c * n.z - s * n.x}; }
+__device__ __forceinline__ P3 rotz_back(P3 n, float c, float s) { return P3{c * n.x - s * n.y, s * n.x + c * n.y, n.z}; }
+__device__ __forceinline__ P3 rotq_back(P3 n, float xx, float xy, float xz, float yx, float yy, float yz,
+                                        float zx, float zy, float zz) {
+    return P3{n.x + 2.f * (xx * n.x + yx * n.y + zx * n.z),
+              n.y + 2.f * (xy * n.x + yy * n.y + zy * n.z),
+              n.z + 2.f * (xz * n.x + yz * n.y + zz * n.z)};
+}
+__device__ __forceinline__ P3 neg3(P3 n) { return P3{-n.x, -n.y, -n.z}; }
+
+// blend of the two normalised child normals of a glata_* node (:369-374, :397-402)
+__device__ __forceinline__ P3 glata_blend(P3 n0, P3 n1, float h) {
+    float d0 = r_length_3(n0.x, n0.y, n0.z), d1 = r_length_3(n1.x, n1.y, n1.z);
+    return P3{mixf(d0 * n0.x, d1 * n1.x, h), mixf(d0 * n0.y, d1 * n1.y, h), mixf(d0 * n0.z, d1 * n1.z, h)};
+}
+// the blend parameter h of a glata_* node (:356, :384)
+__device__ __forceinline__ float glata_h(float d0, float d1, float k, bool komunajo) {
+    float q = (d0 - d1) / k;
+    return (komunajo ? (1.f + q) : (1.f - q)) * .5f;
+}
+
+// kernel_SetRays, Source/cuda_kernels.cu:740-760
+__device__ __forceinline__ void make_ray(const Camera& cam, uint32_t width, uint32_t height, int x, int y,
+                                         P3& p, P3& d) {
+    float X = .5f * (float)(2 * x - (int)width + 1);
+    float Y = .5f * (float)(2 * y - (int)height + 1);
+    float Z = cam.depth;
+    P3 pos{X * cam.wvec[0] + Y * cam.hvec[0], X * cam.wvec[1] + Y * cam.hvec[1], X * cam.wvec[2] + Y * cam.hvec[2]};
+    P3 dp{Z * cam.dir[0], Z * cam.dir[1], Z * cam.dir[2]};
+    float R_1 = r_length_3(pos.x + dp.x, pos.y + dp.y, pos.z + dp.z);
+    d = P3{R_1 * (pos.x + dp.x), R_1 * (pos.y + dp.y), R_1 * (pos.z + dp.z)};
+    p = P3{pos.x + cam.pos[0], pos.y + cam.pos[1], pos.z + cam.pos[2]};
+}
+
+// float -> unsigned char of Source/cuda_kernels.cu:694-699, out-of-range values saturate
+__device__ __forceinline__ uint32_t to_u8(float v) {
+    return !(v > -1.f) ? 0u : (v >= 256.f ? 255u : (uint32_t)(int)v);
+}
+
+enum : int { M_PRIMARY = 0, M_SHADOW = 1, M_DONE = 2 };
+
+}  // namespace rm

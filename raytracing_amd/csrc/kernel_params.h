@@ -1,7 +1,9 @@
 // kernel_params.h - launch parameters shared by capi.cpp and raymarch_kernels.hip.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "scene_program.h"
 
@@ -36,6 +38,7 @@ struct RenderParams {
     Camera cam;
 };
 
+#ifndef __HIPCC_RTC__
 hipError_t launch_render(const RenderParams& prm, dim3 grid, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_eval_points(const RenderParams& prm, int which, uint32_t idx, const float* xyz, uint32_t count,
                               float* dist_out, float* norm_out, size_t lds_bytes, hipStream_t stream);
@@ -43,5 +46,6 @@ hipError_t launch_eval_rays(const RenderParams& prm, const int* xy, uint32_t cou
 // raise the kernels' dynamic-LDS ceiling when a scene needs more than the 64 KiB default
 hipError_t configure_lds(size_t lds_bytes);
 hipError_t kernel_attributes(int* vgprs, int* scratch_bytes);
+#endif
 
 }  // namespace rm

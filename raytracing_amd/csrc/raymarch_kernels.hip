@@ -1,4 +1,5 @@
-// raymarch_kernels.hip - gfx950 (CDNA4) kernels of the per-pixel raymarch path.
+// raymarch_kernels.hip - gfx950 (CDNA4) kernels of the per-pixel raymarch path,
+// ahead-of-time build: the generic evaluators (distance program + tree walker).
 //
 // One fused kernel replaces the reference's kernel_SetRays + kernel_Process
 // (Source/cuda_kernels.cu:598-762): it derives each pixel's ray in registers,
@@ -8,578 +9,23 @@
 //
 // Arithmetic is fp32 with IEEE add/mul/div/sqrt and NO contraction (build with
 // -ffp-contract=off): every expression keeps the reference's operation order,
-// so frames are bit-identical to the CPU restatement in oracle/.
+// so frames are bit-identical to the CPU restatement.
 //
-// Execution shape (wave64):
-//   * a wavefront owns an 8x8 pixel tile, a 256-thread workgroup a 16x16 block;
-//   * every lane is a small state machine (primary march -> waiting for a
-//     normal -> shadow march -> done).  Primary and shadow marches need the
-//     same thing, DIST(root, point), so lanes in either phase share one
-//     wave-uniform run of the distance program per loop trip instead of
-//     serialising the reference's nested loops (:626, :660) lane by lane;
-//   * lanes that reached a surface wait until enough of the wave needs a
-//     normal, then the tree walker runs for exactly those lanes.
+// device_math.h    primitives, transforms, conventions
+// device_interp.h  distance program interpreter, tree walker
+// device_render.h  the kernel body (also compiled at run time against per-scene
+//                  generated code, see jit.cpp)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/rm_types.h"
-#include "kernel_params.h"
-#include "scene_program.h"
+#include "device_interp.h"
+#include "device_render.h"
 
 namespace rm {
 
-struct P3 { float x, y, z; };
-
-// ---- scalar helpers (same arithmetic conventions as the CPU restatement) ---------------------
-
-__device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ float min2(float a, float b) { return (b < a) ? b : a; }   // std::min
-__device__ __forceinline__ float max2(float a, float b) { return (a < b) ? b : a; }   // std::max
-// Include/cuda_defines.cuh:49-53
-__device__ __forceinline__ float length_3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
-__device__ __forceinline__ float r_length_3(float x, float y, float z) { return 1.f / sqrtf(x * x + y * y + z * z); }
-__device__ __forceinline__ float length_2(float x, float y) {
-    return (float)sqrt((double)x * (double)x + (double)y * (double)y);
-}
-// Source/cuda_kernels.cu:38-44
-__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
-    return ax * bx + ay * by + az * bz;
-}
-__device__ __forceinline__ float mixf(float a, float b, float x) { return a + x * (b - a); }
-
-// ---- primitives (Source/cuda_kernels.cu:72-136), q = query point -------------
-
-__device__ __forceinline__ float sfero_dist(P3 q, float r) { return length_3(q.x, q.y, q.z) - r; }
-
-__device__ __forceinline__ float kubo_dist(P3 p, float bx, float by, float bz) {
-    float qx = fabsf(p.x) - bx, qy = fabsf(p.y) - by, qz = fabsf(p.z) - bz;
-    float inside = max2(qx, max2(qy, qz));
-    float outside = length_3(max2(qx, 0.f), max2(qy, 0.f), max2(qz, 0.f));
-    return (qx < 0.f && qy < 0.f && qz < 0.f) ? inside : outside;
-}
-
-__device__ __forceinline__ float cilindro_dist(P3 p, float r, float h) {
-    float qx = length_2(p.x, p.y) - r, qy = fabsf(p.z) - h;
-    float inside = qx > qy ? qx : qy;
-    float outside = length_2(max2(qx, 0.f), max2(qy, 0.f));
-    return (qx < 0.f && qy < 0.f) ? inside : outside;
-}
-
-__device__ __forceinline__ float ebeno_dist(P3 p, float nx, float ny, float nz) {
-    return dot3(nx, ny, nz, p.x, p.y, p.z);
-}
-
-// smooth union / intersection (Source/cuda_kernels.cu:356-359, :384-387)
-__device__ __forceinline__ float glata(float d0, float d1, float k, bool komunajo) {
-    float q = (d0 - d1) / k;
-    float h = (komunajo ? (1.f + q) : (1.f - q)) * .5f;
-    float m = mixf(d0, d1, h);
-    float e = k * h * (1.f - h);
-    float blended = komunajo ? (m + e) : (m - e);
-    return h > 1.f ? d0 : (h < 0.f ? d1 : blended);
-}
-
-// ---- transforms (Source/cuda_kernels.cu:409-413,430-432,454-456,478-480,527-530,577-581)
-
-__device__ __forceinline__ P3 movo(P3 p, float tx, float ty, float tz) { return P3{p.x - tx, p.y - ty, p.z - tz}; }
-__device__ __forceinline__ P3 rotx(P3 p, float c, float s) { return P3{p.x, c * p.y + s * p.z, -s * p.y + c * p.z}; }
-__device__ __forceinline__ P3 roty(P3 p, float c, float s) { return P3{-s * p.z + c * p.x, p.y, c * p.z + s * p.x}; }
-__device__ __forceinline__ P3 rotz(P3 p, float c, float s) { return P3{c * p.x + s * p.y, -s * p.x + c * p.y, p.z}; }
-__device__ __forceinline__ P3 rotq(P3 p, float xx, float xy, float xz, float yx, float yy, float yz,
-                                   float zx, float zy, float zz) {
-    return P3{p.x + 2.f * (xx * p.x + xy * p.y + xz * p.z),
-              p.y + 2.f * (yx * p.x + yy * p.y + yz * p.z),
-              p.z + 2.f * (zx * p.x + zy * p.y + zz * p.z)};
-}
-__device__ __forceinline__ P3 ripeto(P3 p, float ax, float ay, float az, float aa) {
-    float N = floorf(dot3(ax, ay, az, p.x, p.y, p.z) / aa + .5f);
-    return P3{p.x - N * ax, p.y - N * ay, p.z - N * az};
-}
-
-// =============================================================================
-// Wave-uniform distance program (scene_program.h).  Every lane of the wave must
-// call this together: `pc` and every slot word are wave-uniform.
-//
-// Fetch: one 32-byte slot = one s_load_dwordx8 into SGPRs, issued a whole slot
-// ahead of its use (the scalar data cache answers in ~250 cycles on gfx950; the
-// loads of a slot's operands must never sit on the dependent path).  The load is
-// written as inline asm because the compiler would split it and wait for the
-// opcode word first.  Operands are used straight from SGPRs by the VALU.
-//
-// Combine: the running value A starts at +inf (program start and after every
-// push), so "set" is "min" and both kinds are one v_med3_f32 with the third
-// operand -inf (min) or +inf (max).
-//
-// `stack` points at this lane's column of the workgroup's LDS stack; level k of
-// it lives at stack[k * RM_BLOCK_THREADS].
-// =============================================================================
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ u32x8 fetch_slot(const Slot* prog, uint32_t byte_offset) {
-    u32x8 v;
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(prog), "s"(byte_offset));
-    return v;
-}
-// the fetched registers may not be read (or copied) before this
-__device__ __forceinline__ void await_slot(u32x8& v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
-}
-
-struct Machine {
-    P3 F, P;          // frame point, work point
-    float A, B;       // running value, register copy of value slot 0
-    float tx, ty;     // rows x,y of a rotacioQ in flight
-};
-
-__device__ __forceinline__ float chain(float a, float v, float sel) { return __builtin_amdgcn_fmed3f(a, v, sel); }
-
-// Executes one slot.  Returns the number of slots to skip after it (portanta_sfero only).
-template <bool SRC_F>
-__device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* stack) {
-    const uint32_t w0 = w[0], op = w0 & 0xff, slot = w0 >> F_SLOT_SHIFT;
-    const P3 S = SRC_F ? m.F : m.P;
-    const float f1 = as_f(w[1]), f2 = as_f(w[2]), f3 = as_f(w[3]), f4 = as_f(w[4]),
-                f5 = as_f(w[5]), f6 = as_f(w[6]), f7 = as_f(w[7]);
-    // -inf continues a min chain, +inf a max chain
-    const float sel = as_f((w0 & (COMB_MAX << F_COMB_SHIFT)) ? 0x7f800000u : 0xff800000u);
-    const uint32_t sign = (w0 & F_NEG) ? 0x80000000u : 0u;
-    uint32_t skip = 0;
-    bool wrote_p = false;
-    switch (op) {
-    case OP_MOVO:    m.P = movo(S, f1, f2, f3); wrote_p = true; break;
-    case OP_ROTX:    m.P = rotx(S, f1, f2); wrote_p = true; break;
-    case OP_ROTY:    m.P = roty(S, f1, f2); wrote_p = true; break;
-    case OP_ROTZ:    m.P = rotz(S, f1, f2); wrote_p = true; break;
-    case OP_ROTQ_XY:          // rows x and y of P = p + 2*(Q p); the point itself is still needed for row z
-        m.tx = S.x + 2.f * (f1 * S.x + f2 * S.y + f3 * S.z);
-        m.ty = S.y + 2.f * (f4 * S.x + f5 * S.y + f6 * S.z);
-        break;
-    case OP_ROTQ_Z:
-        m.P = P3{m.tx, m.ty, S.z + 2.f * (f1 * S.x + f2 * S.y + f3 * S.z)};
-        wrote_p = true;
-        break;
-    case OP_RIPETO:  m.P = ripeto(S, f1, f2, f3, f4); wrote_p = true; break;
-    case OP_SETF:    m.F = m.P; break;
-    case OP_SFERO:   m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, sfero_dist(movo(S, f1, f2, f3), f4)) ^ sign), sel); break;
-    case OP_KUBO:    m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, kubo_dist(movo(S, f1, f2, f3), f4, f5, f6)) ^ sign), sel); break;
-    case OP_CILINDRO:m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, cilindro_dist(movo(S, f1, f2, f3), f4, f5)) ^ sign), sel); break;
-    case OP_EBENO:   m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, ebeno_dist(movo(S, f1, f2, f3), f4, f5, f6)) ^ sign), sel); break;
-    case OP_PUSHA_R: m.B = m.A; m.A = __builtin_inff(); break;
-    case OP_POPC_R:  m.A = chain(m.B, m.A, sel); break;
-    case OP_PUSHA:   stack[slot * RM_BLOCK_THREADS] = m.A; m.A = __builtin_inff(); break;
-    case OP_POPC:    m.A = chain(stack[slot * RM_BLOCK_THREADS], m.A, sel); break;
-    case OP_NEG:     m.A = -m.A; break;
-    case OP_GLATA_R: m.A = glata(m.B, m.A, f1, (w0 & F_NEG) != 0); break;
-    case OP_GLATA:   m.A = glata(stack[slot * RM_BLOCK_THREADS], m.A, f1, (w0 & F_NEG) != 0); break;
-    case OP_PUSHF:
-        stack[slot * RM_BLOCK_THREADS] = m.F.x;
-        stack[(slot + 1) * RM_BLOCK_THREADS] = m.F.y;
-        stack[(slot + 2) * RM_BLOCK_THREADS] = m.F.z;
-        m.F = m.P;
-        break;
-    case OP_POPF:
-        m.F.x = stack[slot * RM_BLOCK_THREADS];
-        m.F.y = stack[(slot + 1) * RM_BLOCK_THREADS];
-        m.F.z = stack[(slot + 2) * RM_BLOCK_THREADS];
-        break;
-    case OP_PORTANTA: {            // Source/cuda_kernels.cu:53-61
-        m.P = movo(S, f1, f2, f3);
-        float d = length_3(m.P.x, m.P.y, m.P.z) - f4;
-        stack[slot * RM_BLOCK_THREADS] = d;
-        // no lane inside the bounding sphere: the child's slots are dead for this wave
-        if (__builtin_amdgcn_ballot_w64(d <= RM_MIN_DIST) == 0) skip = w[5];
-        break;
-    }
-    case OP_PORTANTA_END: {
-        float d = stack[slot * RM_BLOCK_THREADS];
-        m.A = (d <= RM_MIN_DIST) ? m.A : d;
-        break;
-    }
-    default: break;
-    }
-    if (wrote_p && (w0 & F_DST_F)) m.F = m.P;
-    return skip;
-}
-
-__device__ __forceinline__ float run_program(const Slot* __restrict__ prog, P3 E, float* stack) {
-    Machine m;
-    m.F = E; m.P = E;
-    m.A = __builtin_inff(); m.B = 0.f; m.tx = 0.f; m.ty = 0.f;
-    uint32_t pc = 0;
-    u32x8 cur = fetch_slot(prog, 0);
-    await_slot(cur);
-    while ((cur[0] & 0xff) != OP_END) {
-        u32x8 nxt = fetch_slot(prog, (pc + 1) * (uint32_t)sizeof(Slot));      // in flight while `cur` executes
-        const uint32_t skip = (cur[0] & F_SRC_F) ? exec_slot<true>(m, cur, stack) : exec_slot<false>(m, cur, stack);
-        pc += 1;
-        if (skip) {                     // rare: the prefetched slot is not the next one
-            await_slot(nxt);
-            pc += skip;
-            nxt = fetch_slot(prog, pc * (uint32_t)sizeof(Slot));
-        }
-        await_slot(nxt);
-        cur = nxt;
-    }
-    return m.A;
-}
-
-// =============================================================================
-// Per-lane tree walker over the LDS tree table: the reference's recursion
-// (Include/defines.h:75-76) unrolled onto an explicit private stack.  Lanes may
-// be at different nodes; used for normals and the child distances that select
-// them, where control flow is per pixel by nature.
-// =============================================================================
-struct WalkStack {
-    uint32_t hdr[kWalkDepth];       // node | child index << 16
-    float acc[kWalkDepth];
-    float x[kWalkDepth], y[kWalkDepth], z[kWalkDepth];
-};
-
-__device__ __forceinline__ P3 tree_transform(uint32_t code, const uint32_t* w, P3 p) {
-    switch (code) {
-    case TC_MOVO:   return movo(p, as_f(w[2]), as_f(w[3]), as_f(w[4]));
-    case TC_ROTX:   return rotx(p, as_f(w[2]), as_f(w[3]));
-    case TC_ROTY:   return roty(p, as_f(w[2]), as_f(w[3]));
-    case TC_ROTZ:   return rotz(p, as_f(w[2]), as_f(w[3]));
-    case TC_ROTQ:   return rotq(p, as_f(w[2]), as_f(w[3]), as_f(w[4]), as_f(w[5]), as_f(w[6]), as_f(w[7]),
-                                as_f(w[8]), as_f(w[9]), as_f(w[10]));
-    default:        return ripeto(p, as_f(w[2]), as_f(w[3]), as_f(w[4]), as_f(w[5]));
-    }
-}
-
-__device__ __forceinline__ float tree_leaf_dist(uint32_t code, const uint32_t* w, P3 p) {
-    switch (code) {
-    case TC_SFERO:    return sfero_dist(p, as_f(w[1]));
-    case TC_KUBO:     return kubo_dist(p, as_f(w[1]), as_f(w[2]), as_f(w[3]));
-    case TC_CILINDRO: return cilindro_dist(p, as_f(w[1]), as_f(w[2]));
-    default:          return ebeno_dist(p, as_f(w[1]), as_f(w[2]), as_f(w[3]));
-    }
-}
-
-// DIST(node `root`, p).  Frames are pushed above `base`.
-__device__ __forceinline__ float walk_dist(const TreeNode* tree, uint32_t root, P3 p, WalkStack& st, int base) {
-    int sp = base;
-    uint32_t node = root;
-    float v = 0.f;
-    for (;;) {
-        // ---- descend until a value is known
-        for (;;) {
-            const uint32_t* w = tree[node].w;
-            const uint32_t code = w[0] & 0xff;
-            if (code >= TC_SFERO && code <= TC_EBENO) { v = tree_leaf_dist(code, w, p); break; }
-            if (code >= TC_MOVO) { p = tree_transform(code, w, p); node = w[1]; continue; }
-            if (code == TC_PORTANTA) {                       // Source/cuda_kernels.cu:53-61
-                P3 q = movo(p, as_f(w[2]), as_f(w[3]), as_f(w[4]));
-                float d = length_3(q.x, q.y, q.z) - as_f(w[5]);
-                if (d <= RM_MIN_DIST) { p = q; node = w[1]; continue; }
-                v = d;
-                break;
-            }
-            // komplemento, kunigajo_N, komunajo_N, glata_*: evaluate child 0 first
-            st.hdr[sp] = node;
-            st.x[sp] = p.x; st.y[sp] = p.y; st.z[sp] = p.z;
-            ++sp;
-            node = w[1];
-        }
-        // ---- hand the value to the waiting frames
-        for (;;) {
-            if (sp == base) return v;
-            const uint32_t hdr = st.hdr[sp - 1];
-            const uint32_t fnode = hdr & 0xffff, k = hdr >> 16;
-            const uint32_t* w = tree[fnode].w;
-            const uint32_t code = w[0] & 0xff, arity = (w[0] >> 8) & 0xff;
-            if (code == TC_KOMPLEMENTO) { v = -v; --sp; continue; }            // :339-341
-            if (code == TC_KUNIGAJO || code == TC_KOMUNAJO) {                  // :141-145 ... :294-306
-                float acc = v;
-                if (k > 0) acc = (code == TC_KUNIGAJO) ? min2(st.acc[sp - 1], v) : max2(st.acc[sp - 1], v);
-                if (k + 1 == arity) { v = acc; --sp; continue; }
-                st.acc[sp - 1] = acc;
-                st.hdr[sp - 1] = fnode | ((k + 1) << 16);
-                p = P3{st.x[sp - 1], st.y[sp - 1], st.z[sp - 1]};
-                node = w[2 + k];
-                break;
-            }
-            // glata_kunigajo_2 / glata_komunajo_2                              // :352-359, :380-387
-            if (k == 0) {
-                st.acc[sp - 1] = v;
-                st.hdr[sp - 1] = fnode | (1u << 16);
-                p = P3{st.x[sp - 1], st.y[sp - 1], st.z[sp - 1]};
-                node = w[2];
-                break;
-            }
-            v = glata(st.acc[sp - 1], v, as_f(w[3]), code == TC_GLATA_KOMUNAJO);
-            --sp;
-        }
-    }
-}
-
-// NORM(node `root`, p), unnormalised as in the reference.
-__device__ __forceinline__ P3 walk_norm(const TreeNode* tree, uint32_t root, P3 p, WalkStack& st) {
-    int sp = 0;
-    uint32_t node = root;
-    P3 N{0.f, 0.f, 0.f};
-    for (;;) {
-        // ---- descend to the leaf whose normal is wanted
-        for (;;) {
-            const uint32_t* w = tree[node].w;
-            const uint32_t code = w[0] & 0xff, arity = (w[0] >> 8) & 0xff;
-            if (code == TC_SFERO) { N = p; break; }                            // :78
-            if (code == TC_KUBO) {                                             // :94-104
-                float qx = fabsf(p.x) - as_f(w[1]), qy = fabsf(p.y) - as_f(w[2]), qz = fabsf(p.z) - as_f(w[3]);
-                float sx = p.x > 0.f ? 1.f : -1.f, sy = p.y > 0.f ? 1.f : -1.f, sz = p.z > 0.f ? 1.f : -1.f;
-                if (qx < 0.f && qy < 0.f && qz < 0.f) {
-                    if (qx > qz) N = (qx > qy) ? P3{sx, 0.f, 0.f} : P3{0.f, sy, 0.f};
-                    else         N = (qy > qz) ? P3{0.f, sy, 0.f} : P3{0.f, 0.f, sz};
-                } else {
-                    N = P3{qx > 0.f ? sx : 0.f, qy > 0.f ? sy : 0.f, qz > 0.f ? sz : 0.f};
-                }
-                break;
-            }
-            if (code == TC_CILINDRO) {                                         // :120-126
-                float qx = length_2(p.x, p.y) - as_f(w[1]), qy = fabsf(p.z) - as_f(w[2]);
-                N = (qx > qy) ? P3{p.x, p.y, 0.f} : P3{0.f, 0.f, p.z > 0.f ? 1.f : -1.f};
-                break;
-            }
-            if (code == TC_EBENO) { N = P3{as_f(w[1]), as_f(w[2]), as_f(w[3])}; break; }   // :135
-            if (code == TC_MOVO || code == TC_RIPETO) { p = tree_transform(code, w, p); node = w[1]; continue; }
-            if (code == TC_PORTANTA) { p = movo(p, as_f(w[2]), as_f(w[3]), as_f(w[4])); node = w[1]; continue; }  // :64-69
-            if (code >= TC_ROTX && code <= TC_ROTQ) {        // rotate in now, rotate the normal back later
-                p = tree_transform(code, w, p);
-                st.hdr[sp++] = node;
-                node = w[1];
-                continue;
-            }
-            if (code == TC_KOMPLEMENTO) { st.hdr[sp++] = node; node = w[1]; continue; }
-            {
-                // combinators: the children's distances decide where the normal comes from.
-                // kunigajo_N / komunajo_N forward to the child with the smallest / largest
-                // distance; ties go to child 1 for arity 2 (:153, :252) and to the earlier
-                // child for arity 3 and 4 (:179,186,217,224,231 / :278,285,316,323,330).
-                const bool nary = code == TC_KUNIGAJO || code == TC_KOMUNAJO;
-                const bool is_min = code == TC_KUNIGAJO;
-                const uint32_t kids = nary ? arity : 2u;
-                float d0 = 0.f, d1 = 0.f, best = 0.f;
-                uint32_t pick = 0;
-                for (uint32_t k = 0; k < kids; ++k) {
-                    float d = walk_dist(tree, w[1 + k], p, st, sp);
-                    if (k == 0) { d0 = d; best = d; continue; }
-                    if (k == 1) d1 = d;
-                    if (kids == 2) pick = (is_min ? (d0 < d) : (d0 > d)) ? 0u : 1u;
-                    else if (is_min ? (best > d) : (best < d)) { best = d; pick = k; }
-                }
-                if (nary) { node = w[1 + pick]; continue; }
-                // glata_*: :362-374, :390-402
-                float q = (d0 - d1) / as_f(w[3]);
-                float h = ((code == TC_GLATA_KOMUNAJO) ? (1.f + q) : (1.f - q)) * .5f;
-                if (h > 1.f) { node = w[1]; continue; }
-                if (h < 0.f) { node = w[2]; continue; }
-                st.hdr[sp] = node;                 // phase 0: normal of child 0 pending
-                st.acc[sp] = h;
-                st.x[sp] = p.x; st.y[sp] = p.y; st.z[sp] = p.z;
-                ++sp;
-                node = w[1];
-            }
-        }
-        // ---- carry the normal back up through the waiting frames
-        for (;;) {
-            if (sp == 0) return N;
-            const uint32_t hdr = st.hdr[sp - 1];
-            const uint32_t fnode = hdr & 0xffff, phase = hdr >> 16;
-            const uint32_t* w = tree[fnode].w;
-            const uint32_t code = w[0] & 0xff;
-            if (code == TC_KOMPLEMENTO) { N = P3{-N.x, -N.y, -N.z}; --sp; continue; }      // :346
-            if (code == TC_ROTX) {                                                          // :443-445
-                float c = as_f(w[2]), s = as_f(w[3]);
-                N = P3{N.x, c * N.y - s * N.z, s * N.y + c * N.z}; --sp; continue;
-            }
-            if (code == TC_ROTY) {                                                          // :467-469
-                float c = as_f(w[2]), s = as_f(w[3]);
-                N = P3{s * N.z + c * N.x, N.y, c * N.z - s * N.x}; --sp; continue;
-            }
-            if (code == TC_ROTZ) {                                                          // :491-493
-                float c = as_f(w[2]), s = as_f(w[3]);
-                N = P3{c * N.x - s * N.y, s * N.x + c * N.y, N.z}; --sp; continue;
-            }
-            if (code == TC_ROTQ) {                                                          // :566-569 (transpose)
-                float xx = as_f(w[2]), xy = as_f(w[3]), xz = as_f(w[4]), yx = as_f(w[5]), yy = as_f(w[6]),
-                      yz = as_f(w[7]), zx = as_f(w[8]), zy = as_f(w[9]), zz = as_f(w[10]);
-                N = P3{N.x + 2.f * (xx * N.x + yx * N.y + zx * N.z),
-                       N.y + 2.f * (xy * N.x + yy * N.y + zy * N.z),
-                       N.z + 2.f * (xz * N.x + yz * N.y + zz * N.z)};
-                --sp; continue;
-            }
-            // glata blend
-            if (phase == 0) {
-                p = P3{st.x[sp - 1], st.y[sp - 1], st.z[sp - 1]};
-                st.x[sp - 1] = N.x; st.y[sp - 1] = N.y; st.z[sp - 1] = N.z;   // keep n0
-                st.hdr[sp - 1] = fnode | (1u << 16);
-                node = w[2];
-                break;
-            }
-            {
-                float h = st.acc[sp - 1];
-                P3 n0{st.x[sp - 1], st.y[sp - 1], st.z[sp - 1]}, n1 = N;
-                float d0 = r_length_3(n0.x, n0.y, n0.z), d1 = r_length_3(n1.x, n1.y, n1.z);
-                N = P3{mixf(d0 * n0.x, d1 * n1.x, h), mixf(d0 * n0.y, d1 * n1.y, h), mixf(d0 * n0.z, d1 * n1.z, h)};
-                --sp;
-            }
-        }
-    }
-}
-
-// ---- workgroup prologue: stage the tree table in LDS -------------------------
-
-__device__ __forceinline__ void stage_tree(const TreeNode* __restrict__ src, uint32_t n_nodes, uint32_t* lds) {
-    const uint4* s = reinterpret_cast<const uint4*>(src);
-    uint4* d = reinterpret_cast<uint4*>(lds);
-    for (uint32_t i = threadIdx.x; i < n_nodes * 3; i += RM_BLOCK_THREADS) d[i] = s[i];
-    __syncthreads();
-}
-
-// kernel_SetRays, Source/cuda_kernels.cu:740-760
-__device__ __forceinline__ void make_ray(const Camera& cam, uint32_t width, uint32_t height, int x, int y,
-                                         P3& p, P3& d) {
-    float X = .5f * (float)(2 * x - (int)width + 1);
-    float Y = .5f * (float)(2 * y - (int)height + 1);
-    float Z = cam.depth;
-    P3 pos{X * cam.wvec[0] + Y * cam.hvec[0], X * cam.wvec[1] + Y * cam.hvec[1], X * cam.wvec[2] + Y * cam.hvec[2]};
-    P3 dp{Z * cam.dir[0], Z * cam.dir[1], Z * cam.dir[2]};
-    float R_1 = r_length_3(pos.x + dp.x, pos.y + dp.y, pos.z + dp.z);
-    d = P3{R_1 * (pos.x + dp.x), R_1 * (pos.y + dp.y), R_1 * (pos.z + dp.z)};
-    p = P3{pos.x + cam.pos[0], pos.y + cam.pos[1], pos.z + cam.pos[2]};
-}
-
-// float -> unsigned char of Source/cuda_kernels.cu:694-699, out-of-range values saturate
-__device__ __forceinline__ uint32_t to_u8(float v) {
-    return !(v > -1.f) ? 0u : (v >= 256.f ? 255u : (uint32_t)(int)v);
-}
-
-enum : int { M_PRIMARY = 0, M_SHADOW = 1, M_DONE = 2 };
-
-// =============================================================================
-// The frame kernel.
-// =============================================================================
 __global__ void __launch_bounds__(RM_BLOCK_THREADS)
 render_kernel(const RenderParams prm) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const TreeNode* tree = reinterpret_cast<const TreeNode*>(lds);
-    float* stack = reinterpret_cast<float*>(lds + prm.n_nodes * 12) + threadIdx.x;
-    stage_tree(prm.tree, prm.n_nodes, lds);
-
-    // 16x16 pixels per workgroup, one 8x8 tile per wavefront
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = (int)(blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7));
-    const uint32_t ly = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);       // row in the local buffer
-    uint32_t gy = ly;                                                          // row in the image
-    if (prm.band_rows) gy = ((ly / prm.band_rows) * prm.nranks + prm.rank) * prm.band_rows + ly % prm.band_rows;
-    const bool in_image = px < (int)prm.width && gy < prm.height && ly < prm.local_rows;
-
-    P3 pos, rd;
-    make_ray(prm.cam, prm.width, prm.height, px, (int)gy, pos, rd);
-    const P3 light{prm.cam.light[0], prm.cam.light[1], prm.cam.light[2]};
-
-    WalkStack st;
-    float t = 0.f, cd = 0.f, n_l = 0.f, shadow = 1.f;
-    int mode = in_image ? M_PRIMARY : M_DONE, steps = 0;
-    bool need = false;                       // waiting for NORM(root, pos)
-    uint32_t pixel = 0xff000000u, hit = 0;   // Source/cuda_kernels.cu:622
-
-    // the two places a normal is consumed (Source/cuda_kernels.cu:640-658 and :673-691)
-    auto advance_primary = [&]() {                                             // :707-714
-        pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
-        t += cd;
-        ++steps;
-        if (t >= RM_MAX_DIST || steps >= RM_PRIMARY_STEPS) mode = M_DONE;
-    };
-    auto finish = [&]() {                                                      // :693-701
-        float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
-        float L = (float)to_u8(lum);
-        pixel = to_u8(L * RM_MATERIAL_R) | (to_u8(L * RM_MATERIAL_G) << 8) | (to_u8(L * RM_MATERIAL_B) << 16) | 0xff000000u;
-        hit = 1;
-        mode = M_DONE;
-    };
-    auto shadow_tail = [&]() {                                                 // :679-690
-        shadow = min2(shadow, RM_HARDNESS * cd / t);
-        if (shadow < 0.01f) { finish(); return; }
-        pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
-        t += cd;
-        ++steps;
-        if (t >= RM_MAX_DIST || steps >= RM_SHADOW_STEPS) finish();
-    };
-    auto primary_normal = [&](P3 n) {                                          // :640-658
-        if (dot3(n.x, n.y, n.z, rd.x, rd.y, rd.z) < 0.f) {
-            n_l = dot3(n.x, n.y, n.z, light.x, light.y, light.z);
-            shadow = 1.f;
-            const float k = (1 + RM_DELTA) * RM_MIN_DIST;
-            pos.x += k * light.x; pos.y += k * light.y; pos.z += k * light.z;
-            t = k;
-            mode = M_SHADOW;
-            steps = 0;
-        } else {
-            advance_primary();
-        }
-    };
-    auto shadow_normal = [&](P3 n) {                                           // :673-676
-        if (dot3(n.x, n.y, n.z, rd.x, rd.y, rd.z) < RM_MIN_DIST) { shadow = 0.f; finish(); }
-        else shadow_tail();
-    };
-
-    // optional per-wave diagnostics (rm_debug_wave_stats): trips, normal passes, cycles
-    uint32_t st_evals = 0, st_norms = 0, st_norm_cycles = 0;
-    const uint64_t st_t0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
-
-    for (;;) {
-        const bool active = (mode != M_DONE) && !need;
-        const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
-        if (amask != 0) {
-            ++st_evals;
-            // DIST(root, pos) for the whole wave (:627 and :661 share this)
-            float d = (prm.evaluator == 0) ? run_program(prm.program, pos, stack)
-                                           : walk_dist(tree, 0, pos, st, 0);
-            if (active) {
-                cd = d;
-                if (mode == M_PRIMARY) {
-                    if (cd < RM_MIN_DIST) {                                    // :629
-                        if (cd < -0.f) primary_normal(P3{-rd.x, -rd.y, -rd.z});  // :630-633
-                        else need = true;
-                    } else {
-                        advance_primary();
-                    }
-                } else {
-                    if (8 * cd < RM_MIN_DIST) {                                // :662
-                        if (cd < -0.f) shadow_normal(P3{-light.x, -light.y, -light.z});   // :663-666
-                        else need = true;
-                    } else {
-                        shadow_tail();
-                    }
-                }
-            }
-        }
-        const unsigned long long nmask = __builtin_amdgcn_ballot_w64(need);
-        const unsigned long long run = __builtin_amdgcn_ballot_w64((mode != M_DONE) && !need);
-        if (nmask == 0) { if (run == 0) break; continue; }
-        if (run != 0 && (uint32_t)__builtin_popcountll(nmask) < prm.norm_batch) continue;
-        const uint64_t st_n0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
-        ++st_norms;
-        if (need) {                                                            // :635-637, :668-670
-            P3 N = walk_norm(tree, 0, pos, st);
-            float R_1 = r_length_3(N.x, N.y, N.z);
-            P3 n{R_1 * N.x, R_1 * N.y, R_1 * N.z};
-            if (mode == M_PRIMARY) primary_normal(n); else shadow_normal(n);
-            need = false;
-        }
-        if (prm.wave_stats) st_norm_cycles += (uint32_t)(__builtin_amdgcn_s_memtime() - st_n0);
-    }
-
-    if (prm.wave_stats && lane == 0) {
-        uint32_t* o = prm.wave_stats + 4 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
-        o[0] = st_evals; o[1] = st_norms; o[2] = (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0); o[3] = st_norm_cycles;
-    }
-
-    if (in_image) {                                                            // :717
-        *reinterpret_cast<uint32_t*>(prm.rgba + (size_t)ly * prm.pitch + (size_t)px * 4) = pixel;
-        if (prm.hit) prm.hit[(size_t)ly * prm.hit_pitch + (size_t)px] = (uint8_t)hit;
-    }
+    render_body<InterpScene>(prm);
 }
 
 // =============================================================================

@@ -19,7 +19,9 @@
 //      slots are fetched with scalar loads and their operands sit in SGPRs.
 //      It evaluates DIST(root, p), the innermost cost of the march.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 namespace rm {
 

@@ -41,9 +41,17 @@ def same_floats(a, b):
     return np.all((a == b) | (((a | b) & 0x7FFFFFFF) == 0) | (np.isnan(fa) & np.isnan(fb)))
 
 
-def gpu_render(nodes, w, h, info, evaluator=0, norm_batch=None):
+# the three device evaluators of DIST(root, p): per-scene generated code (hiprtc),
+# the wave-uniform distance program, the per-lane tree walker -> (jit mode, evaluator)
+PATHS = {"jit": (2, 0), "program": (0, 0), "walker": (0, 1)}
+
+
+def gpu_render(nodes, w, h, info, path="jit", norm_batch=None):
+    jit, evaluator = PATHS[path]
     with api.Raymarching(w, h) as rm:
+        rm.set_jit(jit)
         rm.set_nodes(nodes)
+        assert rm.scene_stats()["jit"] == (1 if jit else 0)
         rm.set_info(info)
         rm.enable_hit_mask(True)
         rm.set_evaluator(evaluator)
@@ -61,12 +69,16 @@ def test_node_kat(name):
     want_d = O.dist_many(table, 0, pts)
     want_n = O.norm_many(table, 0, pts)
     with api.Raymarching(64, 64) as rm:
+        rm.set_jit(2)
         rm.set_nodes(table)
         d_prog, _ = rm.eval_points(pts, 0, which=0, want_norm=False)
         d_walk, n_walk = rm.eval_points(pts, 0, which=1, want_norm=True)
+        d_jit, n_jit = rm.eval_points(pts, 0, which=2, want_norm=True)
     assert same_floats(d_walk, want_d), "tree walker DIST differs from the oracle"
     assert same_floats(d_prog, want_d), "distance program DIST differs from the oracle"
     assert same_floats(n_walk, want_n), "tree walker NORM differs from the oracle"
+    assert same_floats(d_jit, want_d), "generated code DIST differs from the oracle"
+    assert same_floats(n_jit, want_n), "generated code NORM differs from the oracle"
 
 
 def test_node_kat_inner_nodes():
@@ -96,12 +108,12 @@ def test_set_rays_kat():
 
 
 @pytest.mark.parametrize("name", ["chair", "infinity"])
-@pytest.mark.parametrize("evaluator", [0, 1])
-def test_stock_frame_640x480(stock_scenes, name, evaluator):
+@pytest.mark.parametrize("path", sorted(PATHS))
+def test_stock_frame_640x480(stock_scenes, name, path):
     """SURVEY.md 8d config 1 on the GPU: byte-identical frame, golden sha256, hit count."""
     info = O.default_info(1, 0)
-    rgba, hit, _ = gpu_render(stock_scenes[name], 640, 480, info, evaluator)
-    ref = O.render(stock_scenes[name], 640, 480, info, threads=os.cpu_count() or 4)
+    rgba, hit, _ = gpu_render(stock_scenes[name], 640, 480, info, path)
+    ref = O.render(stock_scenes[name], 640, 480, info, threads=min(16, os.cpu_count() or 4))
     assert int(hit.sum()) == GOLDEN_HITS[(name, 640, 480)]
     assert np.array_equal(hit, ref["hit"]), "hit mask differs: %d px" % int((hit != ref["hit"]).sum())
     assert np.array_equal(rgba, ref["rgba"]), "colour differs: %d px" % int((rgba != ref["rgba"]).any(-1).sum())
@@ -111,10 +123,11 @@ def test_stock_frame_640x480(stock_scenes, name, evaluator):
 
 
 @pytest.mark.parametrize("name", ["chair", "infinity"])
-def test_stock_hits_1080p(stock_scenes, name):
+@pytest.mark.parametrize("path", ["jit", "program"])
+def test_stock_hits_1080p(stock_scenes, name, path):
     """config 2: hit count recorded from the reference's host-side run at 1920x1080."""
     info = O.default_info(1, 0)
-    rgba, hit, _ = gpu_render(stock_scenes[name], 1920, 1080, info)
+    rgba, hit, _ = gpu_render(stock_scenes[name], 1920, 1080, info, path)
     assert int(hit.sum()) == GOLDEN_HITS[(name, 1920, 1080)]
     # rows sampled across the frame, byte-for-byte against the oracle
     for y0 in (0, 270, 536, 540, 812, 1079):
@@ -137,24 +150,25 @@ def test_csg1024_frame():
     table = scenes.csg1024()
     info = O.default_info(1, 0)
     w, h = 256, 144
-    rgba, hit, _ = gpu_render(table, w, h, info)
-    ref = O.render(table, w, h, info, threads=os.cpu_count() or 4)
+    rgba, hit, _ = gpu_render(table, w, h, info, "program")     # too large for generated code
+    ref = O.render(table, w, h, info, threads=min(16, os.cpu_count() or 4))
     assert ref["hit"].sum() > 0
     assert np.array_equal(hit, ref["hit"])
     assert np.array_equal(rgba, ref["rgba"])
-    rgba_w, hit_w, _ = gpu_render(table, w, h, info, evaluator=1)
+    rgba_w, hit_w, _ = gpu_render(table, w, h, info, "walker")
     assert np.array_equal(rgba_w, rgba) and np.array_equal(hit_w, hit)
 
 
 @pytest.mark.parametrize("name", ["mixed_kinds", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
-def test_kat_scene_frames(name):
+@pytest.mark.parametrize("path", ["jit", "program"])
+def test_kat_scene_frames(name, path):
     """Whole frames of the nested test scenes (LDS value slots, saved frames, bounding spheres)."""
     table = kat_scenes.tables()[name]
     info = O.default_info(3, 11)
     info["StartPos"] = (-40.0, 3.0, 2.0)
     w, h = 200, 120
-    rgba, hit, _ = gpu_render(table, w, h, info)
-    ref = O.render(table, w, h, info, threads=os.cpu_count() or 4)
+    rgba, hit, _ = gpu_render(table, w, h, info, path)
+    ref = O.render(table, w, h, info, threads=min(16, os.cpu_count() or 4))
     assert np.array_equal(hit, ref["hit"])
     assert np.array_equal(rgba, ref["rgba"])
 
@@ -162,8 +176,8 @@ def test_kat_scene_frames(name):
 def test_ragged_sizes(stock_scenes):
     """Image sizes that are not multiples of the 16x16 workgroup block."""
     info = O.default_info(1, 0)
-    for (w, h) in [(1, 1), (17, 9), (250, 131)]:
-        rgba, hit, _ = gpu_render(stock_scenes["chair"], w, h, info)
+    for (w, h), path in [((1, 1), "jit"), ((17, 9), "program"), ((250, 131), "jit"), ((250, 131), "program")]:
+        rgba, hit, _ = gpu_render(stock_scenes["chair"], w, h, info, path)
         ref = O.render(stock_scenes["chair"], w, h, info)
         assert np.array_equal(rgba, ref["rgba"]) and np.array_equal(hit, ref["hit"])
 
