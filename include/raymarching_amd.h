@@ -163,13 +163,31 @@ int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_sour
  * not depend on it. */
 int rm_set_norm_batch(rm_ctx* ctx, int lanes);
 
+/* Tuning: how many idle lanes (finished pixels) a wavefront collects before it
+ * stores them and pulls new pixels from the tile queue (1..64).  Results do not
+ * depend on it. */
+int rm_set_refill_lanes(rm_ctx* ctx, int lanes);
+
+/* Tuning: frame-to-frame scheduling feedback.  A pixel whose rays took `steps`
+ * march steps or more marks its 8x8 tile as heavy; the next frame starts with
+ * those tiles (at most `max_tiles` of them, <= 65536), because the longest rays
+ * bound the frame time.  Only the order of the work depends on the previous
+ * frame, never a pixel value.  steps = 0xffffffff or max_tiles = 0 turns it off.
+ * Takes effect from the next frame; forgets the current history. */
+int rm_set_heavy_first(rm_ctx* ctx, unsigned steps, unsigned max_tiles);
+
+/* Tuning: a wavefront that carries a ray older than `trips` march-loop trips
+ * raises its issue priority (long rays bound the frame time).  0xffffffff
+ * disables it.  Results do not depend on it. */
+int rm_set_boost_age(rm_ctx* ctx, unsigned trips);
+
 /* Which evaluator computes root distances: 0 = wave-uniform scene program
  * (default), 1 = per-lane tree walker (diagnostic; identical results). */
 int rm_set_evaluator(rm_ctx* ctx, int which);
 
-/* Diagnostics: render one frame and return, per wavefront, 4 dwords: march
- * loop trips, normal passes, shader cycles in the kernel, cycles in normal
- * passes.  With host_out NULL only *n_waves is set. */
+/* Diagnostics: render one frame and return, per (persistent) wavefront, 4
+ * dwords: march loop trips, normal passes, shader cycles in the kernel, cycles
+ * in normal passes.  With host_out NULL only *n_waves is set. */
 int rm_debug_wave_stats(rm_ctx* ctx, uint32_t* host_out, size_t cap_waves, size_t* n_waves);
 
 const char* rm_status_string(int status);

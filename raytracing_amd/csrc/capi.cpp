@@ -38,8 +38,17 @@ struct rm_ctx {
 
     size_t band_rows = 0; int rank = 0, nranks = 1;
     size_t local_rows = 0;
-    uint32_t norm_batch = 16, evaluator = 0;
+    uint32_t norm_batch = 1, evaluator = 0, refill_lanes = 64, boost_age = 48;
     size_t lds_bytes = 0;
+
+    // tile scheduler (device_render.h): three counter sets and three heavy-tile lists used by
+    // frames seq, seq+1, seq+2 in turn, and one stamp per tile.  A frame zeroes the next
+    // frame's set itself, so no memset sits between frames.
+    uint32_t* sched = nullptr;        // [3 sets][3 lists of heavy_cap][stamps]
+    uint32_t seq = 2;                 // frame sequence number; stamps start at 0, so seq-1 matches none
+    uint32_t heavy_cap = 1u << 16, heavy_cost = 64;
+    size_t n_stamps = 0;
+    int cus = 1, blocks_per_cu = 1;   // of the device / of the ahead-of-time kernel at lds_bytes
     int vgprs = 0, scratch = 0;       // of the ahead-of-time (interpreter) kernel
 
     int jit_mode = 1;                 // 0 never, 1 when the scene is small enough, 2 required
@@ -51,6 +60,7 @@ struct rm_ctx {
 namespace {
 
 constexpr size_t kLdsLimit = 160 * 1024 - 1024;   // LDS per CU on gfx950, less a margin
+constexpr uint32_t kHeavyCapMax = 1u << 16;       // entries per heavy-tile list
 
 size_t count_local_rows(size_t height, size_t band_rows, int rank, int nranks) {
     if (!band_rows) return height;
@@ -77,6 +87,51 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;
     p.cam = c->cam;
+    p.refill_lanes = c->refill_lanes;
+    p.boost_age = c->boost_age;
+    const uint32_t cur = c->seq % 3, prev = (c->seq + 2) % 3, next = (c->seq + 1) % 3;
+    uint32_t* lists = c->sched + 3 * RM_SET_DWORDS;
+    p.set_cur = c->sched + cur * RM_SET_DWORDS;
+    p.set_prev = c->sched + prev * RM_SET_DWORDS;
+    p.set_next = c->sched + next * RM_SET_DWORDS;
+    p.heavy_cur = lists + static_cast<size_t>(cur) * kHeavyCapMax;
+    p.heavy_prev = lists + static_cast<size_t>(prev) * kHeavyCapMax;
+    p.heavy_cap = c->heavy_cap;
+    p.heavy_cost = c->heavy_cost;
+    p.stamp = lists + 3 * static_cast<size_t>(kHeavyCapMax);
+    p.seq = c->seq;
+}
+
+size_t sched_bytes(const rm_ctx* c) {
+    return (3 * RM_SET_DWORDS + 3 * static_cast<size_t>(kHeavyCapMax) + c->n_stamps) * sizeof(uint32_t);
+}
+
+// forget which tiles were heavy (the tile numbering changed, or the sequence number is about to wrap)
+hipError_t reset_schedule(rm_ctx* c) {
+    c->seq = 2;
+    return hipMemsetAsync(c->sched, 0, sched_bytes(c), c->stream);
+}
+
+// persistent grid: what the chip holds at once, or fewer when the image has few tiles
+unsigned render_blocks(const rm_ctx* c, bool jit) {
+    const size_t tiles = ((c->width + 7) / 8) * ((c->local_rows + 7) / 8);
+    const size_t want = (tiles + 3) / 4;                     // four wavefronts per workgroup, a tile each
+    const size_t resident = static_cast<size_t>(c->cus) * static_cast<size_t>(jit ? c->jit.blocks_per_cu : c->blocks_per_cu);
+    return static_cast<unsigned>(want < resident ? want : resident);
+}
+
+// one frame on the context's stream; *waves (optional) receives the wavefronts launched
+int launch_frame(rm_ctx* c, uint32_t* wave_stats, size_t* waves) {
+    rm::RenderParams p;
+    fill_params(c, p);
+    p.wave_stats = wave_stats;
+    const bool jit = c->jit_active && c->evaluator == 0;
+    const unsigned blocks = render_blocks(c, jit);
+    if (waves) *waves = static_cast<size_t>(blocks) * 4;
+    hipError_t e = jit ? rm::jit_launch_render(c->jit, p, blocks, c->stream)
+                       : rm::launch_render(p, blocks, c->lds_bytes, c->stream);
+    if (e == hipSuccess && ++c->seq >= 0xfffffff0u) e = reset_schedule(c);
+    return static_cast<int>(e);
 }
 
 int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
@@ -121,6 +176,8 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     c->d_program = d_prog; c->d_tree = d_tree;
     c->n_nodes = static_cast<uint32_t>(built.tree.size());
     c->lds_bytes = lds;
+    int occ = 0;
+    c->blocks_per_cu = (rm::render_occupancy(lds, &occ) == hipSuccess && occ > 0) ? occ : 1;
     c->scene = std::move(built);
     c->have_scene = true;
     return RM_OK;
@@ -147,7 +204,8 @@ int rm_load_sce(const char* path, rm_node* out, size_t cap, size_t* n) {
 int rm_save_sce(const char* path, const rm_node* nodes, size_t n) { return rm::save_sce(path, nodes, n); }
 
 int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
-    if (!out || width == 0 || height == 0 || width > (1u << 20) || height > (1u << 20)) return RM_ERR_INVALID_ARG;
+    if (!out || width == 0 || height == 0 || width > (1u << 20) || height > (1u << 20) ||
+        width * height > (size_t(1) << 30)) return RM_ERR_INVALID_ARG;       // tile and pixel indices are 32-bit
     *out = nullptr;
     HIP_TRY(hipSetDevice(device));
     rm_ctx* c = new (std::nothrow) rm_ctx;
@@ -158,6 +216,10 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc(&c->fb, width * height * 4);
+    c->n_stamps = ((width + 7) / 8) * ((height + 7) / 8);
+    if (e == hipSuccess) e = hipMalloc(&c->sched, sched_bytes(c));
+    if (e == hipSuccess) e = hipMemset(c->sched, 0, sched_bytes(c));
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) e = rm::kernel_attributes(&c->vgprs, &c->scratch);
     if (e != hipSuccess) { rm_destroy(c); return e == hipErrorInvalidDeviceFunction ? RM_ERR_NO_KERNEL : static_cast<int>(e); }
     c->stream = c->own_stream;
@@ -175,6 +237,7 @@ int rm_destroy(rm_ctx* c) {
     if (c->d_tree) (void)hipFree(c->d_tree);
     if (c->fb) (void)hipFree(c->fb);
     if (c->hit) (void)hipFree(c->hit);
+    if (c->sched) (void)hipFree(c->sched);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -224,10 +287,14 @@ int rm_set_info(rm_ctx* c, const rm_rays_info* info) {
 
 int rm_set_bands(rm_ctx* c, size_t band_rows, int rank, int nranks) {
     if (!c) return RM_ERR_INVALID_ARG;
-    if (band_rows == 0) { c->band_rows = 0; c->rank = 0; c->nranks = 1; c->local_rows = c->height; return RM_OK; }
-    if ((band_rows % 16) || nranks < 1 || rank < 0 || rank >= nranks) return RM_ERR_INVALID_ARG;
-    c->band_rows = band_rows; c->rank = rank; c->nranks = nranks;
-    c->local_rows = count_local_rows(c->height, band_rows, rank, nranks);
+    if (band_rows != 0 && ((band_rows % 16) || nranks < 1 || rank < 0 || rank >= nranks)) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (band_rows == 0) { c->band_rows = 0; c->rank = 0; c->nranks = 1; c->local_rows = c->height; }
+    else {
+        c->band_rows = band_rows; c->rank = rank; c->nranks = nranks;
+        c->local_rows = count_local_rows(c->height, band_rows, rank, nranks);
+    }
+    HIP_TRY(reset_schedule(c));          // tiles are numbered over the local rows
     return RM_OK;
 }
 
@@ -253,11 +320,7 @@ int rm_process_async(rm_ctx* c) {
     if (!c->out || c->out_pitch < c->width * 4 || !c->d_program || !c->d_tree ||
         c->n_nodes != c->scene.tree.size() || c->local_rows > c->height) return RM_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    rm::RenderParams p;
-    fill_params(c, p);
-    dim3 grid(static_cast<unsigned>((c->width + 15) / 16), static_cast<unsigned>((c->local_rows + 15) / 16));
-    if (c->jit_active && c->evaluator == 0) return static_cast<int>(rm::jit_launch_render(c->jit, p, grid, c->stream));
-    return static_cast<int>(rm::launch_render(p, grid, c->lds_bytes, c->stream));
+    return launch_frame(c, nullptr, nullptr);
 }
 
 int rm_synchronize(rm_ctx* c) {
@@ -348,21 +411,16 @@ int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char
 int rm_debug_wave_stats(rm_ctx* c, uint32_t* host_out, size_t cap_waves, size_t* n_waves) {
     if (!c || !n_waves) return RM_ERR_INVALID_ARG;
     if (!c->have_scene || !c->have_info) return RM_ERR_NOT_READY;
-    const size_t gx = (c->width + 15) / 16, gy = (c->local_rows + 15) / 16, waves = gx * gy * 4;
+    const size_t waves = static_cast<size_t>(render_blocks(c, c->jit_active && c->evaluator == 0)) * 4;
     *n_waves = waves;
     if (!host_out) return RM_OK;
     if (cap_waves < waves) return RM_ERR_INVALID_ARG;
+    if (c->local_rows == 0) return RM_OK;
     HIP_TRY(hipSetDevice(c->device));
     uint32_t* d = nullptr;
     HIP_TRY(hipMalloc(&d, waves * 16));
-    rm::RenderParams p;
-    fill_params(c, p);
-    p.wave_stats = d;
     hipError_t e = hipMemsetAsync(d, 0, waves * 16, c->stream);
-    if (e == hipSuccess)
-        e = (c->jit_active && c->evaluator == 0)
-                ? rm::jit_launch_render(c->jit, p, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), c->stream)
-                : rm::launch_render(p, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), c->lds_bytes, c->stream);
+    if (e == hipSuccess) e = static_cast<hipError_t>(launch_frame(c, d, nullptr));
     if (e == hipSuccess) e = hipMemcpyAsync(host_out, d, waves * 16, hipMemcpyDeviceToHost, c->stream);
     hipError_t s2 = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = s2;
@@ -405,6 +463,27 @@ int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_sour
 int rm_set_norm_batch(rm_ctx* c, int lanes) {
     if (!c || lanes < 1 || lanes > 64) return RM_ERR_INVALID_ARG;
     c->norm_batch = static_cast<uint32_t>(lanes);
+    return RM_OK;
+}
+
+int rm_set_refill_lanes(rm_ctx* c, int lanes) {
+    if (!c || lanes < 1 || lanes > 64) return RM_ERR_INVALID_ARG;
+    c->refill_lanes = static_cast<uint32_t>(lanes);
+    return RM_OK;
+}
+
+int rm_set_heavy_first(rm_ctx* c, unsigned steps, unsigned max_tiles) {
+    if (!c || max_tiles > kHeavyCapMax) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    c->heavy_cost = steps;
+    c->heavy_cap = max_tiles;
+    HIP_TRY(reset_schedule(c));
+    return RM_OK;
+}
+
+int rm_set_boost_age(rm_ctx* c, unsigned trips) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    c->boost_age = trips;
     return RM_OK;
 }
 

@@ -191,6 +191,9 @@ hipError_t load_module(const std::vector<char>& code, JitKernels* out) {
     if (e == hipSuccess) {
         (void)hipFuncGetAttribute(&out->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, out->render);
         (void)hipFuncGetAttribute(&out->scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, out->render);
+        int occ = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, out->render, RM_BLOCK_THREADS, 0) == hipSuccess && occ > 0)
+            out->blocks_per_cu = occ;
     }
     return e;
 }
@@ -217,8 +220,10 @@ bool jit_build_code(const std::string& arch, const std::string& source, std::vec
     if (hiprtcCreateProgram(&prog, source.c_str(), "rm_scene.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return false;
     const std::string arch_opt = "--offload-arch=" + arch;
     // same arithmetic contract as the ahead-of-time build: no contraction, IEEE sqrt and division
-    const char* opts[] = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math" };
-    hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+    // (the atomic optimizer is off for the tile queue's sake: device_render.h)
+    const char* opts[] = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None" };
+    hiprtcResult r = hiprtcCompileProgram(prog, 7, opts);
     size_t log_size = 0;
     if (log && hiprtcGetProgramLogSize(prog, &log_size) == HIPRTC_SUCCESS && log_size > 1) {
         log->resize(log_size);
@@ -273,10 +278,10 @@ hipError_t jit_compile(int device, const std::string& scene_source, JitKernels* 
     return hipSuccess;
 }
 
-hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, dim3 grid, hipStream_t stream) {
+hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, unsigned blocks, hipStream_t stream) {
     RenderParams copy = prm;
     void* args[] = { &copy };
-    return hipModuleLaunchKernel(k.render, grid.x, grid.y, 1, RM_BLOCK_THREADS, 1, 1, 0, stream, args, nullptr);
+    return hipModuleLaunchKernel(k.render, blocks, 1, 1, RM_BLOCK_THREADS, 1, 1, 0, stream, args, nullptr);
 }
 
 hipError_t jit_launch_eval_points(const JitKernels& k, const RenderParams& prm, const float* xyz, uint32_t count,

@@ -27,6 +27,7 @@ struct JitKernels {
     hipFunction_t render = nullptr;
     hipFunction_t eval_points = nullptr;
     int vgprs = 0, scratch = 0;
+    int blocks_per_cu = 1;      // resident workgroups per CU of `render`
 };
 
 // HIP source of the d<i>/n<i> function pairs of every reachable node plus the
@@ -42,7 +43,7 @@ bool jit_build_code(const std::string& arch, const std::string& source, std::vec
 // Returns hipSuccess, or an error with the compiler log in *log.
 hipError_t jit_compile(int device, const std::string& scene_source, JitKernels* out, std::string* log);
 
-hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, dim3 grid, hipStream_t stream);
+hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, unsigned blocks, hipStream_t stream);
 hipError_t jit_launch_eval_points(const JitKernels& k, const RenderParams& prm, const float* xyz, uint32_t count,
                                   float* dist_out, float* norm_out, hipStream_t stream);
 

@@ -7,7 +7,15 @@
 
 #include "scene_program.h"
 
-#define RM_BLOCK_THREADS 256     // 4 wavefronts: a 16x16 pixel block, one 8x8 tile per wave
+#define RM_BLOCK_THREADS 256     // 4 wavefronts per workgroup
+#define RM_TILE_PIXELS   64      // work unit of the tile queue: one 8x8 pixel tile
+#define RM_QUEUE_HEADS   8       // tile queue heads (one per XCD under round-robin workgroup placement)
+#define RM_QUEUE_STRIDE  32      // dwords between counters: each on a 128-byte line of its own
+// one scheduler set = 16 counters: [0..7] natural-order heads, [8] head of the heavy list,
+// [9] length of the heavy list written by the frame that owns the set
+#define RM_SET_HEAVY_HEAD  (8 * RM_QUEUE_STRIDE)
+#define RM_SET_HEAVY_COUNT (9 * RM_QUEUE_STRIDE)
+#define RM_SET_DWORDS      (16 * RM_QUEUE_STRIDE)
 
 namespace rm {
 
@@ -35,11 +43,26 @@ struct RenderParams {
     uint8_t* rgba;  size_t pitch;
     uint8_t* hit;   size_t hit_pitch;
     uint32_t* wave_stats;         // optional diagnostics, 4 dwords per wavefront
+    // tile scheduler (device_render.h): frame `seq` owns set_cur (all zero when it starts), reads the
+    // heavy list the previous frame wrote, and zeroes set_next for the frame after it
+    uint32_t* set_cur;
+    const uint32_t* set_prev;
+    uint32_t* set_next;
+    const uint32_t* heavy_prev;   // tiles that held a long ray in the previous frame: rendered first
+    uint32_t* heavy_cur;          // the same list for the next frame, written by this one
+    uint32_t heavy_cap;           // entries per list
+    uint32_t heavy_cost;          // march steps from which a pixel makes its tile heavy
+    uint32_t* stamp;              // per tile: the last frame in which it was heavy
+    uint32_t seq;                 // frame sequence number (>= 2)
+    uint32_t refill_lanes;        // idle lanes a wave collects before it pulls new pixels
+    uint32_t boost_age;           // loop trips after which a ray raises its wave's issue priority
     Camera cam;
 };
 
 #ifndef __HIPCC_RTC__
-hipError_t launch_render(const RenderParams& prm, dim3 grid, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_render(const RenderParams& prm, unsigned blocks, size_t lds_bytes, hipStream_t stream);
+// resident workgroups per CU of the ahead-of-time render kernel with `lds_bytes` of dynamic LDS
+hipError_t render_occupancy(size_t lds_bytes, int* blocks_per_cu);
 hipError_t launch_eval_points(const RenderParams& prm, int which, uint32_t idx, const float* xyz, uint32_t count,
                               float* dist_out, float* norm_out, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_eval_rays(const RenderParams& prm, const int* xy, uint32_t count, float* out, hipStream_t stream);

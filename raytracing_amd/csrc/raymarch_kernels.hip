@@ -67,9 +67,14 @@ __global__ void eval_rays_kernel(const RenderParams prm, const int* __restrict__
 
 // ---- launchers (called from capi.cpp) -----------------------------------------
 
-hipError_t launch_render(const RenderParams& prm, dim3 grid, size_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(render_kernel, grid, dim3(RM_BLOCK_THREADS), lds_bytes, stream, prm);
+hipError_t launch_render(const RenderParams& prm, unsigned blocks, size_t lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(RM_BLOCK_THREADS), lds_bytes, stream, prm);
     return hipGetLastError();
+}
+
+hipError_t render_occupancy(size_t lds_bytes, int* blocks_per_cu) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(render_kernel),
+                                                        RM_BLOCK_THREADS, lds_bytes);
 }
 
 hipError_t launch_eval_points(const RenderParams& prm, int which, uint32_t idx, const float* xyz, uint32_t count,

@@ -1,0 +1,91 @@
+// valu_peak.hip - what one SIMD of gfx950 issues per cycle for the instruction
+// kinds the march kernel is made of (fp32, no contraction).  Build:
+//   hipcc -O3 --offload-arch=gfx950 -o valu_peak valu_peak.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define REP8(x) x x x x x x x x
+#define N_ITER 2048
+
+typedef float float2_ __attribute__((ext_vector_type(2)));
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k(float* out, float seed, unsigned long long* cyc) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float2_ p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+    const float c = seed * 0.5f;
+    const float2_ c2 = {c, c};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < N_ITER; ++i) {
+        if (KIND == 0) {        // v_add_f32, 8 independent chains, 8 instr per body x8
+            REP8(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                              "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+        } else if (KIND == 1) { // v_pk_add_f32
+            REP8(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                              "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(c2));)
+        } else if (KIND == 2) { // v_fma_f32
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                              "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+        } else if (KIND == 3) { // v_sqrt_f32
+            REP8(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n"
+                              "v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+        } else if (KIND == 4) { // one dependent chain of v_add_f32
+            REP8(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n"
+                              "v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n v_add_f32 %0, %0, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c));)
+        } else if (KIND == 5) { // v_pk_mul_f32 with an SGPR pair operand
+            REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                              "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(c2));)
+        } else if (KIND == 6) { // v_cndmask + v_cmp pairs
+            REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                              "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc");)
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int KIND>
+void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, double flops_per_instr) {
+    const int blocks = 256 * waves_per_simd;      // 256 threads = 4 waves = one per SIMD of a CU
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 1.0f, d_cyc);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 1.0f, d_cyc);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> cyc(blocks);
+    hipMemcpy(cyc.data(), d_cyc, blocks * 8, hipMemcpyDeviceToHost);
+    double mean = 0; for (auto c : cyc) mean += c; mean /= blocks;
+    const double instr = 64.0 * N_ITER;           // per wave
+    const double total_instr = instr * blocks * 4;
+    printf("%-14s waves/SIMD %d  %8.3f ms  cycles/instr/wave %.2f  => SIMD issue %.2f cyc/instr  %.1f Tinstr-lanes/s  %.1f TFLOP/s  clock %.2f GHz\n",
+           name, waves_per_simd, ms, mean / instr, mean / instr / waves_per_simd, total_instr * 64 / (ms * 1e-3) / 1e12,
+           total_instr * 64 * flops_per_instr / (ms * 1e-3) / 1e12, mean / (ms * 1e-3) / 1e9);
+}
+
+int main() {
+    float* d_out; unsigned long long* d_cyc;
+    hipMalloc(&d_out, 256 * 8 * 256 * 4); hipMalloc(&d_cyc, 256 * 8 * 8);
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_add_f32", w, d_out, d_cyc, 1);
+        run<1>("v_pk_add_f32", w, d_out, d_cyc, 2);
+        run<2>("v_fma_f32", w, d_out, d_cyc, 2);
+        run<3>("v_sqrt_f32", w, d_out, d_cyc, 1);
+        run<4>("add dependent", w, d_out, d_cyc, 1);
+        run<5>("v_pk_mul sgpr", w, d_out, d_cyc, 2);
+        run<6>("cmp+cndmask", w, d_out, d_cyc, 0);
+    }
+    return 0;
+}

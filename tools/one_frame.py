@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
-"""Renders a workload a few times (profiling target): one_frame.py SCENE W H [REPS] [norm_batch]"""
+"""one_frame.py SCENE W H [frames]: render through the C ABI, compare every frame with the oracle."""
 import os
 import sys
+import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import oracle as O          # camera block only
+from oracle import oracle as O
 from raytracing_amd import api
 
 scene, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-nodes = api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
+frames = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+path = os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce")
+info = O.default_info(1, 0)
+ref = O.render(O.load_sce(path), w, h, info, threads=16)
 with api.Raymarching(w, h) as rm:
-    rm.set_nodes(nodes)
-    rm.set_info(O.default_info(1, 0))
-    if len(sys.argv) > 5:
-        rm.set_norm_batch(int(sys.argv[5]))
-    print([round(rm.process(), 4) for _ in range(reps)], rm.scene_stats())
+    rm.set_nodes(api.load_sce(path))
+    rm.set_info(info)
+    print("stats", rm.scene_stats(), flush=True)
+    for k in range(frames):
+        t0 = time.time()
+        ms = rm.process()
+        got = rm.read_pixels()
+        bad = int((got != ref["rgba"]).any(-1).sum())
+        print("frame %d: kernel %.3f ms (wall %.3f s), %d pixels differ from the oracle" % (k, ms, time.time() - t0, bad), flush=True)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the render kernel over a few workloads and knob settings (GPU box)."""
+"""Times the render kernel over a few workloads and knob settings (GPU box):
+perf_probe.py [scene ...]"""
 import os
 import sys
 
@@ -8,17 +9,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O          # camera block only
-from raytracing_amd import api
+from raytracing_amd import api, scenes as S
 
 
-def time_it(nodes, w, h, info, reps=5, **knobs):
+def time_it(nodes, w, h, info, reps=7, jit=1, **knobs):
     with api.Raymarching(w, h) as rm:
+        rm.set_jit(jit)
         rm.set_nodes(nodes)
         rm.set_info(info)
         if "evaluator" in knobs:
             rm.set_evaluator(knobs["evaluator"])
         if "norm_batch" in knobs:
             rm.set_norm_batch(knobs["norm_batch"])
+        if "heavy" in knobs:
+            rm.set_heavy_first(knobs["heavy"])
+        if "boost" in knobs:
+            rm.set_boost_age(knobs["boost"])
+        if "refill" in knobs:
+            rm.set_refill_lanes(knobs["refill"])
         rm.process()
         ms = sorted(rm.process() for _ in range(reps))
         return ms[len(ms) // 2]
@@ -27,17 +35,28 @@ def time_it(nodes, w, h, info, reps=5, **knobs):
 def main():
     info = O.default_info(1, 0)
     G = os.path.join(ROOT, "tests", "golden", "scenes")
-    scenes = {n: api.load_sce(os.path.join(G, n + ".sce")) for n in ("chair", "infinity", "csg1024")}
-    jobs = [("chair", 3840, 2160), ("chair", 1920, 1080), ("chair", 640, 480), ("infinity", 3840, 2160), ("csg1024", 960, 540)]
-    only = sys.argv[1:] 
+    scenes = {n: api.load_sce(os.path.join(G, n + ".sce")) for n in ("chair", "infinity")}
+    scenes["csg1024"] = S.csg1024()
+    jobs = [("chair", 3840, 2160), ("chair", 1920, 1080), ("chair", 7680, 4320), ("infinity", 3840, 2160), ("csg1024", 960, 540)]
+    only = sys.argv[1:]
     for name, w, h in jobs:
         if only and name not in only:
             continue
         base = time_it(scenes[name], w, h, info)
-        line = "%-9s %4dx%-4d  program %8.3f ms  %8.1f Mrays/s" % (name, w, h, base, w * h / base / 1e3)
-        for nb in (1, 4, 32, 64):
-            line += "  nb%d %.3f" % (nb, time_it(scenes[name], w, h, info, norm_batch=nb))
-        line += "  walker %.3f" % time_it(scenes[name], w, h, info, reps=3, evaluator=1)
+        line = "%-9s %4dx%-4d  default %8.3f ms  %8.1f Mrays/s |" % (name, w, h, base, w * h / base / 1e3)
+        for rf in (1, 4, 8, 16, 32, 64):
+            line += " rf%d %.3f" % (rf, time_it(scenes[name], w, h, info, refill=rf))
+        line += " |"
+        for ba in (8, 24, 96, 0xffffffff):
+            line += " ba%d %.3f" % (ba if ba < 1000 else -1, time_it(scenes[name], w, h, info, boost=ba))
+        line += " | rf64+noboost %.3f |" % time_it(scenes[name], w, h, info, boost=0xffffffff, refill=64)
+        for hv in (16, 32, 128, 256, 0xffffffff):
+            line += " hv%d %.3f" % (hv if hv < 1000 else -1, time_it(scenes[name], w, h, info, heavy=hv))
+        line += " | hv-1,ba-1 %.3f |" % time_it(scenes[name], w, h, info, heavy=0xffffffff, boost=0xffffffff)
+        for nb in (1, 8, 32, 64):
+            line += " nb%d %.3f" % (nb, time_it(scenes[name], w, h, info, norm_batch=nb))
+        if name != "csg1024":
+            line += " | program %.3f" % time_it(scenes[name], w, h, info, reps=3, jit=0)
         print(line, flush=True)
 
 
