@@ -163,21 +163,15 @@ int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_sour
  * not depend on it. */
 int rm_set_norm_batch(rm_ctx* ctx, int lanes);
 
-/* Tuning: how many idle lanes (finished pixels) a wavefront collects before it
- * stores them and pulls new pixels from the tile queue (1..64).  Results do not
- * depend on it. */
-int rm_set_refill_lanes(rm_ctx* ctx, int lanes);
+/* Tuning: frame-to-frame scheduling feedback (on by default).  Every frame files
+ * its 8x8 tiles by cost (march-loop trips); the next frame renders them from the
+ * costliest down, because the longest tiles bound the frame time.  Only the
+ * order of the work depends on the previous frame, never a pixel value.
+ * enable = 0: always natural tile order.  Forgets the current history. */
+int rm_set_heavy_first(rm_ctx* ctx, int enable);
 
-/* Tuning: frame-to-frame scheduling feedback.  A pixel whose rays took `steps`
- * march steps or more marks its 8x8 tile as heavy; the next frame starts with
- * those tiles (at most `max_tiles` of them, <= 65536), because the longest rays
- * bound the frame time.  Only the order of the work depends on the previous
- * frame, never a pixel value.  steps = 0xffffffff or max_tiles = 0 turns it off.
- * Takes effect from the next frame; forgets the current history. */
-int rm_set_heavy_first(rm_ctx* ctx, unsigned steps, unsigned max_tiles);
-
-/* Tuning: a wavefront that carries a ray older than `trips` march-loop trips
- * raises its issue priority (long rays bound the frame time).  0xffffffff
+/* Tuning: a wavefront whose tile has run for more than `trips` march-loop trips
+ * raises its issue priority (long tiles bound the frame time).  0xffffffff
  * disables it.  Results do not depend on it. */
 int rm_set_boost_age(rm_ctx* ctx, unsigned trips);
 

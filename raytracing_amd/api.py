@@ -28,7 +28,7 @@ EXPORTS = [
     "rm_local_rows", "rm_enable_hit_mask", "rm_process", "rm_process_async", "rm_synchronize",
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
-    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_refill_lanes", "rm_set_boost_age", "rm_set_heavy_first", "rm_set_jit", "rm_jit_log", "rm_jit_check",
+    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_set_jit", "rm_jit_log", "rm_jit_check",
 ]
 
 
@@ -90,9 +90,8 @@ def lib():
             "rm_flatten_scene": [vp, sz, C.POINTER(SceneStats), C.c_char_p, sz],
             "rm_set_norm_batch": [vp, i32],
             "rm_set_evaluator": [vp, i32],
-            "rm_set_refill_lanes": [vp, i32],
             "rm_set_boost_age": [vp, C.c_uint],
-            "rm_set_heavy_first": [vp, C.c_uint, C.c_uint],
+            "rm_set_heavy_first": [vp, i32],
             "rm_eval_points": [vp, i32, sz, vp, sz, vp, vp],
             "rm_eval_rays": [vp, vp, sz, vp],
             "rm_debug_wave_stats": [vp, vp, sz, C.POINTER(sz)],
@@ -229,11 +228,8 @@ class Raymarching:
     def set_norm_batch(self, lanes):
         _check(lib().rm_set_norm_batch(self._ctx, lanes), "rm_set_norm_batch")
 
-    def set_refill_lanes(self, lanes):
-        _check(lib().rm_set_refill_lanes(self._ctx, lanes), "rm_set_refill_lanes")
-
-    def set_heavy_first(self, steps, max_tiles=1 << 16):
-        _check(lib().rm_set_heavy_first(self._ctx, steps, max_tiles), "rm_set_heavy_first")
+    def set_heavy_first(self, enable=True):
+        _check(lib().rm_set_heavy_first(self._ctx, 1 if enable else 0), "rm_set_heavy_first")
 
     def set_boost_age(self, trips):
         _check(lib().rm_set_boost_age(self._ctx, trips), "rm_set_boost_age")

@@ -38,16 +38,18 @@ struct rm_ctx {
 
     size_t band_rows = 0; int rank = 0, nranks = 1;
     size_t local_rows = 0;
-    uint32_t norm_batch = 1, evaluator = 0, refill_lanes = 64, boost_age = 48;
+    uint32_t norm_batch = 1, evaluator = 0;
     size_t lds_bytes = 0;
 
-    // tile scheduler (device_render.h): three counter sets and three heavy-tile lists used by
-    // frames seq, seq+1, seq+2 in turn, and one stamp per tile.  A frame zeroes the next
-    // frame's set itself, so no memset sits between frames.
-    uint32_t* sched = nullptr;        // [3 sets][3 lists of heavy_cap][stamps]
-    uint32_t seq = 2;                 // frame sequence number; stamps start at 0, so seq-1 matches none
-    uint32_t heavy_cap = 1u << 16, heavy_cost = 64;
-    size_t n_stamps = 0;
+    // tile scheduler (device_render.h): three counter sets and three groups of tile lists used by
+    // frames seq, seq+1, seq+2 in turn.  A frame zeroes the next frame's set itself, so no memset
+    // sits between frames.
+    uint32_t* sched = nullptr;        // [3 sets][3 x ([8 heads][8 buckets][list_cap] + [overflow_cap])]
+    uint32_t seq = 0;                 // frame sequence number
+    uint32_t list_cap = 0, overflow_cap = 0;
+    bool feedback = true;             // frames file their tiles by cost for the next frame
+    bool history = false;             // the previous frame did, with the same tile numbering
+    uint32_t boost_age = 48;
     int cus = 1, blocks_per_cu = 1;   // of the device / of the ahead-of-time kernel at lds_bytes
     int vgprs = 0, scratch = 0;       // of the ahead-of-time (interpreter) kernel
 
@@ -60,7 +62,10 @@ struct rm_ctx {
 namespace {
 
 constexpr size_t kLdsLimit = 160 * 1024 - 1024;   // LDS per CU on gfx950, less a margin
-constexpr uint32_t kHeavyCapMax = 1u << 16;       // entries per heavy-tile list
+
+size_t list_group_dwords(const rm_ctx* c) {
+    return static_cast<size_t>(RM_QUEUE_HEADS) * RM_COST_BUCKETS * c->list_cap + c->overflow_cap;
+}
 
 size_t count_local_rows(size_t height, size_t band_rows, int rank, int nranks) {
     if (!band_rows) return height;
@@ -87,29 +92,28 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;
     p.cam = c->cam;
-    p.refill_lanes = c->refill_lanes;
     p.boost_age = c->boost_age;
     const uint32_t cur = c->seq % 3, prev = (c->seq + 2) % 3, next = (c->seq + 1) % 3;
     uint32_t* lists = c->sched + 3 * RM_SET_DWORDS;
     p.set_cur = c->sched + cur * RM_SET_DWORDS;
     p.set_prev = c->sched + prev * RM_SET_DWORDS;
     p.set_next = c->sched + next * RM_SET_DWORDS;
-    p.heavy_cur = lists + static_cast<size_t>(cur) * kHeavyCapMax;
-    p.heavy_prev = lists + static_cast<size_t>(prev) * kHeavyCapMax;
-    p.heavy_cap = c->heavy_cap;
-    p.heavy_cost = c->heavy_cost;
-    p.stamp = lists + 3 * static_cast<size_t>(kHeavyCapMax);
-    p.seq = c->seq;
+    p.lists_cur = lists + cur * list_group_dwords(c);
+    p.lists_prev = lists + prev * list_group_dwords(c);
+    p.list_cap = c->list_cap;
+    p.overflow_cap = c->overflow_cap;
+    p.feedback = c->feedback ? 1u : 0u;
+    p.ordered = (c->feedback && c->history) ? 1u : 0u;
 }
 
 size_t sched_bytes(const rm_ctx* c) {
-    return (3 * RM_SET_DWORDS + 3 * static_cast<size_t>(kHeavyCapMax) + c->n_stamps) * sizeof(uint32_t);
+    return (3 * RM_SET_DWORDS + 3 * list_group_dwords(c)) * sizeof(uint32_t);
 }
 
-// forget which tiles were heavy (the tile numbering changed, or the sequence number is about to wrap)
+// forget the previous frame's tile lists (the tile numbering changed, or feedback was switched)
 hipError_t reset_schedule(rm_ctx* c) {
-    c->seq = 2;
-    return hipMemsetAsync(c->sched, 0, sched_bytes(c), c->stream);
+    c->history = false;
+    return hipMemsetAsync(c->sched, 0, 3 * RM_SET_DWORDS * sizeof(uint32_t), c->stream);
 }
 
 // persistent grid: what the chip holds at once, or fewer when the image has few tiles
@@ -130,7 +134,7 @@ int launch_frame(rm_ctx* c, uint32_t* wave_stats, size_t* waves) {
     if (waves) *waves = static_cast<size_t>(blocks) * 4;
     hipError_t e = jit ? rm::jit_launch_render(c->jit, p, blocks, c->stream)
                        : rm::launch_render(p, blocks, c->lds_bytes, c->stream);
-    if (e == hipSuccess && ++c->seq >= 0xfffffff0u) e = reset_schedule(c);
+    if (e == hipSuccess) { ++c->seq; c->history = c->feedback; }
     return static_cast<int>(e);
 }
 
@@ -216,7 +220,10 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipMalloc(&c->fb, width * height * 4);
-    c->n_stamps = ((width + 7) / 8) * ((height + 7) / 8);
+    // a head sees about an eighth of the tiles: a quarter per list leaves room for imbalance,
+    // and what does not fit goes to the overflow list, which can hold every tile
+    c->overflow_cap = static_cast<uint32_t>(((width + 7) / 8) * ((height + 7) / 8));
+    c->list_cap = c->overflow_cap / 4 + 16;
     if (e == hipSuccess) e = hipMalloc(&c->sched, sched_bytes(c));
     if (e == hipSuccess) e = hipMemset(c->sched, 0, sched_bytes(c));
     if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
@@ -466,17 +473,10 @@ int rm_set_norm_batch(rm_ctx* c, int lanes) {
     return RM_OK;
 }
 
-int rm_set_refill_lanes(rm_ctx* c, int lanes) {
-    if (!c || lanes < 1 || lanes > 64) return RM_ERR_INVALID_ARG;
-    c->refill_lanes = static_cast<uint32_t>(lanes);
-    return RM_OK;
-}
-
-int rm_set_heavy_first(rm_ctx* c, unsigned steps, unsigned max_tiles) {
-    if (!c || max_tiles > kHeavyCapMax) return RM_ERR_INVALID_ARG;
+int rm_set_heavy_first(rm_ctx* c, int enable) {
+    if (!c) return RM_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    c->heavy_cost = steps;
-    c->heavy_cap = max_tiles;
+    c->feedback = enable != 0;
     HIP_TRY(reset_schedule(c));
     return RM_OK;
 }

@@ -8,14 +8,19 @@
 #include "scene_program.h"
 
 #define RM_BLOCK_THREADS 256     // 4 wavefronts per workgroup
-#define RM_TILE_PIXELS   64      // work unit of the tile queue: one 8x8 pixel tile
+#define RM_TILE_PIXELS   64      // work unit of the tile queue: one 8x8 pixel tile, one wavefront
 #define RM_QUEUE_HEADS   8       // tile queue heads (one per XCD under round-robin workgroup placement)
+#define RM_COST_BUCKETS  8       // tiles are sorted by cost into this many lists per head
 #define RM_QUEUE_STRIDE  32      // dwords between counters: each on a 128-byte line of its own
-// one scheduler set = 16 counters: [0..7] natural-order heads, [8] head of the heavy list,
-// [9] length of the heavy list written by the frame that owns the set
-#define RM_SET_HEAVY_HEAD  (8 * RM_QUEUE_STRIDE)
-#define RM_SET_HEAVY_COUNT (9 * RM_QUEUE_STRIDE)
-#define RM_SET_DWORDS      (16 * RM_QUEUE_STRIDE)
+// One scheduler set = 96 counters (lines):
+//   [0..7]          pull position of head h;  [8] pull position of the overflow list
+//   [16 + 8*h + b]  length of the list (head h, cost bucket b) written by the frame that owns the set
+//   [80]            length of the overflow list written by that frame
+#define RM_SET_PULL(h)     ((h) * RM_QUEUE_STRIDE)
+#define RM_SET_COUNT(h, b) ((16 + 8 * (h) + (b)) * RM_QUEUE_STRIDE)
+#define RM_SET_OVERFLOW    (80 * RM_QUEUE_STRIDE)
+#define RM_SET_LINES       96
+#define RM_SET_DWORDS      (RM_SET_LINES * RM_QUEUE_STRIDE)
 
 namespace rm {
 
@@ -43,19 +48,17 @@ struct RenderParams {
     uint8_t* rgba;  size_t pitch;
     uint8_t* hit;   size_t hit_pitch;
     uint32_t* wave_stats;         // optional diagnostics, 4 dwords per wavefront
-    // tile scheduler (device_render.h): frame `seq` owns set_cur (all zero when it starts), reads the
-    // heavy list the previous frame wrote, and zeroes set_next for the frame after it
+    // tile scheduler (device_render.h): this frame owns set_cur (all zero when it starts), reads the
+    // lists the previous frame wrote (counts in set_prev), and zeroes set_next for the frame after it
     uint32_t* set_cur;
     const uint32_t* set_prev;
     uint32_t* set_next;
-    const uint32_t* heavy_prev;   // tiles that held a long ray in the previous frame: rendered first
-    uint32_t* heavy_cur;          // the same list for the next frame, written by this one
-    uint32_t heavy_cap;           // entries per list
-    uint32_t heavy_cost;          // march steps from which a pixel makes its tile heavy
-    uint32_t* stamp;              // per tile: the last frame in which it was heavy
-    uint32_t seq;                 // frame sequence number (>= 2)
-    uint32_t refill_lanes;        // idle lanes a wave collects before it pulls new pixels
-    uint32_t boost_age;           // loop trips after which a ray raises its wave's issue priority
+    const uint32_t* lists_prev;   // [8 heads][8 buckets][list_cap] then [overflow_cap]: tiles by falling cost
+    uint32_t* lists_cur;          // the same for the next frame, written by this one
+    uint32_t list_cap, overflow_cap;
+    uint32_t ordered;             // 1: hand out lists_prev; 0: no history, natural tile order
+    uint32_t feedback;            // 1: write lists_cur
+    uint32_t boost_age;           // loop trips after which a tile raises its wave's issue priority
     Camera cam;
 };
 

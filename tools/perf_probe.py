@@ -22,11 +22,9 @@ def time_it(nodes, w, h, info, reps=7, jit=1, **knobs):
         if "norm_batch" in knobs:
             rm.set_norm_batch(knobs["norm_batch"])
         if "heavy" in knobs:
-            rm.set_heavy_first(knobs["heavy"])
+            rm.set_heavy_first(bool(knobs["heavy"]))
         if "boost" in knobs:
             rm.set_boost_age(knobs["boost"])
-        if "refill" in knobs:
-            rm.set_refill_lanes(knobs["refill"])
         rm.process()
         ms = sorted(rm.process() for _ in range(reps))
         return ms[len(ms) // 2]
@@ -44,16 +42,11 @@ def main():
             continue
         base = time_it(scenes[name], w, h, info)
         line = "%-9s %4dx%-4d  default %8.3f ms  %8.1f Mrays/s |" % (name, w, h, base, w * h / base / 1e3)
-        for rf in (1, 4, 8, 16, 32, 64):
-            line += " rf%d %.3f" % (rf, time_it(scenes[name], w, h, info, refill=rf))
-        line += " |"
         for ba in (8, 24, 96, 0xffffffff):
             line += " ba%d %.3f" % (ba if ba < 1000 else -1, time_it(scenes[name], w, h, info, boost=ba))
-        line += " | rf64+noboost %.3f |" % time_it(scenes[name], w, h, info, boost=0xffffffff, refill=64)
-        for hv in (16, 32, 128, 256, 0xffffffff):
-            line += " hv%d %.3f" % (hv if hv < 1000 else -1, time_it(scenes[name], w, h, info, heavy=hv))
-        line += " | hv-1,ba-1 %.3f |" % time_it(scenes[name], w, h, info, heavy=0xffffffff, boost=0xffffffff)
-        for nb in (1, 8, 32, 64):
+        line += " | heavy0 %.3f heavy0,ba-1 %.3f |" % (time_it(scenes[name], w, h, info, heavy=0),
+                                                      time_it(scenes[name], w, h, info, heavy=0, boost=0xffffffff))
+        for nb in (2, 8, 64):
             line += " nb%d %.3f" % (nb, time_it(scenes[name], w, h, info, norm_batch=nb))
         if name != "csg1024":
             line += " | program %.3f" % time_it(scenes[name], w, h, info, reps=3, jit=0)
