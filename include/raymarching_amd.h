@@ -38,7 +38,8 @@ enum rm_status {
     RM_ERR_TOO_LARGE   = -5,  /* scene exceeds RM_MAX_NODES or the LDS budget        */
     RM_ERR_NOT_READY   = -6,  /* rm_process before primitives and info were set      */
     RM_ERR_NO_KERNEL   = -7,  /* the HIP code object for gfx950 could not be loaded  */
-    RM_ERR_JIT         = -8   /* run-time compilation of the scene failed            */
+    RM_ERR_JIT         = -8,  /* run-time compilation of the scene failed            */
+    RM_ERR_ARITHMETIC  = -9   /* the device's short sqrt sequence is not IEEE sqrtf  */
 };
 
 #define RM_MAX_NODES 2048     /* reference: 256 (Source/cuda_kernels.cu:607) */
@@ -134,6 +135,7 @@ typedef struct rm_scene_stats {
     uint32_t kernel_vgprs;     /* register footprint reported by the runtime   */
     uint32_t kernel_scratch;   /* private (scratch) bytes per lane             */
     uint32_t jit;              /* 1: the scene runs on per-scene generated code */
+    uint32_t exact_divisors;   /* divisor constants proved for the short quotient */
 } rm_scene_stats;
 int rm_get_scene_stats(rm_ctx* ctx, rm_scene_stats* out);
 
@@ -155,13 +157,28 @@ int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char
 int rm_set_jit(rm_ctx* ctx, int mode);
 int rm_jit_log(rm_ctx* ctx, char* buf, size_t cap);
 /* Host-only: generate and compile the code of a scene for `arch` without a
- * device.  text receives the generated source (want_source != 0) or the log. */
+ * device.  text receives the generated source (want_source & 1) or the log; want_source & 2 generates
+ * as if every divisor constant had been proved on a device (inspection only). */
 int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_source, char* text, size_t cap);
 
 /* Tuning: how many of a wavefront's lanes must be waiting for a surface normal
  * before the wave leaves the march loop to compute them (1..64).  Results do
  * not depend on it. */
 int rm_set_norm_batch(rm_ctx* ctx, int lanes);
+
+/* Arithmetic self-test (no counterpart in the reference).  The kernels take
+ * sqrt and the divisions by scene constants through sequences a third as long
+ * as the compiler's IEEE expansions (csrc/device_math.h: sqrt_exact, div_const)
+ * and must return the same bits.  This runs them against IEEE sqrtf / division
+ * on the device for all 2^32 float bit patterns (sqrt: the argument; division:
+ * the numerator, once per divisor, quotient by RN(1/divisor)) and returns the
+ * mismatch counts: all must be 0.  n <= 64.  Takes about a second. */
+int rm_selftest_math(rm_ctx* ctx, const float* divisors, size_t n, unsigned long long* sqrt_mismatches,
+                     unsigned long long* div_mismatches);
+
+/* enable = 0: scenes uploaded from now on divide by their constants with IEEE
+ * division only (diagnostic; identical results). */
+int rm_set_short_math(rm_ctx* ctx, int enable);
 
 /* Tuning: frame-to-frame scheduling feedback (on by default).  Every frame files
  * its 8x8 tiles by cost (march-loop trips); the next frame renders them from the

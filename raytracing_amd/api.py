@@ -28,13 +28,14 @@ EXPORTS = [
     "rm_local_rows", "rm_enable_hit_mask", "rm_process", "rm_process_async", "rm_synchronize",
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
-    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_set_jit", "rm_jit_log", "rm_jit_check",
+    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_jit", "rm_jit_log", "rm_jit_check",
 ]
 
 
 class SceneStats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("nodes", "reachable", "program_slots", "value_slots",
-                                          "tree_depth", "lds_bytes", "kernel_vgprs", "kernel_scratch", "jit")]
+                                          "tree_depth", "lds_bytes", "kernel_vgprs", "kernel_scratch", "jit",
+                                          "exact_divisors")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -92,6 +93,8 @@ def lib():
             "rm_set_evaluator": [vp, i32],
             "rm_set_boost_age": [vp, C.c_uint],
             "rm_set_heavy_first": [vp, i32],
+            "rm_selftest_math": [vp, vp, sz, C.POINTER(C.c_ulonglong), vp],
+            "rm_set_short_math": [vp, i32],
             "rm_eval_points": [vp, i32, sz, vp, sz, vp, vp],
             "rm_eval_rays": [vp, vp, sz, vp],
             "rm_debug_wave_stats": [vp, vp, sz, C.POINTER(sz)],
@@ -153,11 +156,11 @@ def flatten_scene(nodes, listing_cap=1 << 20):
     return st.as_dict(), buf.value.decode()
 
 
-def jit_check(nodes, arch="gfx950", want_source=False, cap=1 << 20):
+def jit_check(nodes, arch="gfx950", want_source=False, cap=1 << 20, assume_exact_divisors=False):
     """Host-only: generate + compile a scene's code with hiprtc.  Returns (status, source or log)."""
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     buf = C.create_string_buffer(cap)
-    rc = lib().rm_jit_check(_ptr(nodes), nodes.size, arch.encode(), 1 if want_source else 0, buf, cap)
+    rc = lib().rm_jit_check(_ptr(nodes), nodes.size, arch.encode(), (1 if want_source else 0) | (2 if assume_exact_divisors else 0), buf, cap)
     return rc, buf.value.decode(errors="replace")
 
 
@@ -230,6 +233,18 @@ class Raymarching:
 
     def set_heavy_first(self, enable=True):
         _check(lib().rm_set_heavy_first(self._ctx, 1 if enable else 0), "rm_set_heavy_first")
+
+    def selftest_math(self, divisors=()):
+        """(sqrt mismatches, [division mismatches per divisor]) over all 2^32 bit patterns."""
+        d = np.ascontiguousarray(divisors, dtype=np.float32)
+        sq = C.c_ulonglong(0)
+        bad = np.zeros(max(1, d.size), dtype=np.uint64)
+        _check(lib().rm_selftest_math(self._ctx, _ptr(d) if d.size else None, d.size, C.byref(sq), _ptr(bad)),
+               "rm_selftest_math")
+        return sq.value, [int(x) for x in bad[:d.size]]
+
+    def set_short_math(self, enable=True):
+        _check(lib().rm_set_short_math(self._ctx, 1 if enable else 0), "rm_set_short_math")
 
     def set_boost_age(self, trips):
         _check(lib().rm_set_boost_age(self._ctx, trips), "rm_set_boost_age")

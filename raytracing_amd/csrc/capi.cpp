@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -50,6 +52,8 @@ struct rm_ctx {
     bool feedback = true;             // frames file their tiles by cost for the next frame
     bool history = false;             // the previous frame did, with the same tile numbering
     uint32_t boost_age = 48;
+    bool short_math = true;           // scenes may use div_const for divisors the device has proved
+    uint32_t exact_divisors = 0;      // how many of the current scene's divisor constants were
     int cus = 1, blocks_per_cu = 1;   // of the device / of the ahead-of-time kernel at lds_bytes
     int vgprs = 0, scratch = 0;       // of the ahead-of-time (interpreter) kernel
 
@@ -62,6 +66,18 @@ struct rm_ctx {
 namespace {
 
 constexpr size_t kLdsLimit = 160 * 1024 - 1024;   // LDS per CU on gfx950, less a margin
+
+int sqrt_sweep(rm_ctx* c, uint32_t first, unsigned long long count, unsigned long long* bad) {
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof *d));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof *d, c->stream);
+    if (e == hipSuccess) e = rm::launch_verify_sqrt(first, count, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(bad, d, sizeof *d, hipMemcpyDeviceToHost, c->stream);
+    hipError_t s = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = s;
+    (void)hipFree(d);
+    return static_cast<int>(e);
+}
 
 size_t list_group_dwords(const rm_ctx* c) {
     return static_cast<size_t>(RM_QUEUE_HEADS) * RM_COST_BUCKETS * c->list_cap + c->overflow_cap;
@@ -138,10 +154,55 @@ int launch_frame(rm_ctx* c, uint32_t* wave_stats, size_t* waves) {
     return static_cast<int>(e);
 }
 
+// Runs `count` numerators from bit pattern `first` through div_const for every divisor;
+// mismatches[i] receives the count for c[i].  Synchronous.
+hipError_t check_divisors(rm_ctx* c, const std::vector<float>& cs, uint32_t first, unsigned long long count,
+                          std::vector<unsigned long long>& mismatches) {
+    const size_t n = cs.size();
+    mismatches.assign(n, 0);
+    if (!n) return hipSuccess;
+    std::vector<float> rcs(n);
+    for (size_t i = 0; i < n; ++i) rcs[i] = 1.0f / cs[i];
+    float* d_c = nullptr; unsigned long long* d_bad = nullptr;
+    hipError_t e = hipMalloc(&d_c, 2 * n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_bad, n * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, cs.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c + n, rcs.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, n * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = rm::launch_verify_div(d_c, d_c + n, static_cast<uint32_t>(n), first, count, d_bad, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(mismatches.data(), d_bad, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    hipError_t s = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = s;
+    (void)hipFree(d_c); (void)hipFree(d_bad);
+    return e;
+}
+
+// The divisor constants of a scene for which the device proves div_const exact: finite,
+// 2^-20 <= |c| <= 2^20 (so that quotient and residual of a guarded numerator stay normal), and
+// no mismatch over the binade [1,2) of numerators.
+hipError_t exact_divisors(rm_ctx* c, const rm_node* nodes, size_t n, rm::DivisorSet& out) {
+    out.clear();
+    std::vector<float> cand;
+    for (float v : rm::scene_divisors(nodes, n)) {
+        const float m = v < 0 ? -v : v;
+        if (m >= 0x1p-20f && m <= 0x1p20f) cand.push_back(v);      // false for NaN
+    }
+    std::vector<unsigned long long> bad;
+    hipError_t e = check_divisors(c, cand, 0x3f800000u, 1u << 23, bad);
+    if (e != hipSuccess) return e;
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (bad[i] == 0) { uint32_t u; std::memcpy(&u, &cand[i], 4); out.insert(u); }
+    return hipSuccess;
+}
+
 int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
+    HIP_TRY(hipSetDevice(c->device));
+    rm::DivisorSet exact;
+    if (c->short_math) HIP_TRY(exact_divisors(c, nodes, n, exact));
     rm::SceneBuild built;
-    int rc = rm::build_scene(nodes, n, built);
+    int rc = rm::build_scene(nodes, n, built, &exact);
     if (rc != RM_OK) return rc;
+    c->exact_divisors = static_cast<uint32_t>(exact.size());
     const size_t lds = built.tree.size() * sizeof(rm::TreeNode) +
                        static_cast<size_t>(built.value_slots) * RM_BLOCK_THREADS * sizeof(float);
     if (lds > kLdsLimit) return RM_ERR_TOO_LARGE;
@@ -164,7 +225,7 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     rm::JitKernels jit;
     c->jit_log.clear();
     if (c->jit_mode != 0 && built.reachable <= rm::kJitMaxNodes) {
-        const std::string src = rm::generate_scene_source(nodes, n, built.seen.data());
+        const std::string src = rm::generate_scene_source(nodes, n, built.seen.data(), &exact);
         hipError_t je = rm::jit_compile(c->device, src, &jit, &c->jit_log);
         jit_ok = je == hipSuccess;
         if (!jit_ok && c->jit_mode == 2) { (void)hipFree(d_prog); (void)hipFree(d_tree); return RM_ERR_JIT; }
@@ -230,6 +291,18 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     if (e == hipSuccess) e = rm::kernel_attributes(&c->vgprs, &c->scratch);
     if (e != hipSuccess) { rm_destroy(c); return e == hipErrorInvalidDeviceFunction ? RM_ERR_NO_KERNEL : static_cast<int>(e); }
     c->stream = c->own_stream;
+    // sqrt_exact must be IEEE sqrtf on this device: two binades cover every mantissa and both
+    // exponent parities (the sequence scales exactly by powers of four).  Once per device.
+    {
+        static std::mutex mu; static std::set<int> proved;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!proved.count(device)) {
+            unsigned long long bad = 0;
+            int rc = sqrt_sweep(c, 0x3f800000u, 1ull << 24, &bad);
+            if (rc != RM_OK || bad != 0) { rm_destroy(c); return rc != RM_OK ? rc : RM_ERR_ARITHMETIC; }
+            proved.insert(device);
+        }
+    }
     c->out = c->fb; c->out_pitch = width * 4;
     c->local_rows = height;
     *out = c;
@@ -389,6 +462,7 @@ int rm_get_scene_stats(rm_ctx* c, rm_scene_stats* out) {
     out->kernel_vgprs = static_cast<uint32_t>(c->jit_active ? c->jit.vgprs : c->vgprs);
     out->kernel_scratch = static_cast<uint32_t>(c->jit_active ? c->jit.scratch : c->scratch);
     out->jit = c->jit_active ? 1u : 0u;
+    out->exact_divisors = c->exact_divisors;
     return RM_OK;
 }
 
@@ -454,12 +528,19 @@ int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_sour
     int rc = rm::build_scene(nodes, n, built);
     if (rc != RM_OK) return rc;
     if (built.reachable > rm::kJitMaxNodes) return RM_ERR_TOO_LARGE;
-    const std::string scene = rm::generate_scene_source(nodes, n, built.seen.data());
+    // want_source & 2: generate as if the device had proved every divisor in range (ISA inspection only)
+    rm::DivisorSet assumed;
+    if (want_source & 2)
+        for (float v : rm::scene_divisors(nodes, n)) {
+            const float m = v < 0 ? -v : v;
+            if (m >= 0x1p-20f && m <= 0x1p20f) { uint32_t u; std::memcpy(&u, &v, 4); assumed.insert(u); }
+        }
+    const std::string scene = rm::generate_scene_source(nodes, n, built.seen.data(), &assumed);
     std::string log;
     std::vector<char> code;
     const bool ok = rm::jit_build_code(arch ? arch : "gfx950", rm::jit_full_source(scene), &code, &log);
     if (text && cap) {
-        const std::string& src = want_source ? scene : log;
+        const std::string& src = (want_source & 1) ? scene : log;
         size_t k = src.size() < cap - 1 ? src.size() : cap - 1;
         std::memcpy(text, src.data(), k);
         text[k] = 0;
@@ -478,6 +559,25 @@ int rm_set_heavy_first(rm_ctx* c, int enable) {
     HIP_TRY(hipSetDevice(c->device));
     c->feedback = enable != 0;
     HIP_TRY(reset_schedule(c));
+    return RM_OK;
+}
+
+int rm_selftest_math(rm_ctx* c, const float* divisors, size_t n, unsigned long long* sqrt_mismatches,
+                     unsigned long long* div_mismatches) {
+    if (!c || !sqrt_mismatches || (n && (!divisors || !div_mismatches)) || n > 64) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = sqrt_sweep(c, 0u, 1ull << 32, sqrt_mismatches);
+    if (rc != RM_OK) return rc;
+    std::vector<float> cs(divisors, divisors + n);
+    std::vector<unsigned long long> bad;
+    HIP_TRY(check_divisors(c, cs, 0u, 1ull << 32, bad));
+    for (size_t i = 0; i < n; ++i) div_mismatches[i] = bad[i];
+    return RM_OK;
+}
+
+int rm_set_short_math(rm_ctx* c, int enable) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    c->short_math = enable != 0;
     return RM_OK;
 }
 
@@ -504,6 +604,7 @@ const char* rm_status_string(int status) {
     case RM_ERR_NOT_READY: return "primitives and rays_info must be set first";
     case RM_ERR_NO_KERNEL: return "no gfx950 code object for this device";
     case RM_ERR_JIT: return "run-time compilation of the scene failed (see rm_jit_log)";
+    case RM_ERR_ARITHMETIC: return "this device's short sqrt sequence is not IEEE sqrtf (device_math.h)";
     default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
     }
 }

@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
         m.P = P3{m.tx, m.ty, S.z + 2.f * (f1 * S.x + f2 * S.y + f3 * S.z)};
         wrote_p = true;
         break;
-    case OP_RIPETO:  m.P = ripeto(S, f1, f2, f3, f4); wrote_p = true; break;
+    case OP_RIPETO:  m.P = ripeto(S, f1, f2, f3, f4, f5); wrote_p = true; break;
     case OP_SETF:    m.F = m.P; break;
     case OP_SFERO:   m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, sfero_dist(movo(S, f1, f2, f3), f4)) ^ sign), sel); break;
     case OP_KUBO:    m.A = chain(m.A, as_f(__builtin_bit_cast(uint32_t, kubo_dist(movo(S, f1, f2, f3), f4, f5, f6)) ^ sign), sel); break;
@@ -80,8 +80,8 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
     case OP_PUSHA:   stack[slot * RM_BLOCK_THREADS] = m.A; m.A = __builtin_inff(); break;
     case OP_POPC:    m.A = chain(stack[slot * RM_BLOCK_THREADS], m.A, sel); break;
     case OP_NEG:     m.A = -m.A; break;
-    case OP_GLATA_R: m.A = glata(m.B, m.A, f1, (w0 & F_NEG) != 0); break;
-    case OP_GLATA:   m.A = glata(stack[slot * RM_BLOCK_THREADS], m.A, f1, (w0 & F_NEG) != 0); break;
+    case OP_GLATA_R: m.A = glata(m.B, m.A, f1, f2, (w0 & F_NEG) != 0); break;
+    case OP_GLATA:   m.A = glata(stack[slot * RM_BLOCK_THREADS], m.A, f1, f2, (w0 & F_NEG) != 0); break;
     case OP_PUSHF:
         stack[slot * RM_BLOCK_THREADS] = m.F.x;
         stack[(slot + 1) * RM_BLOCK_THREADS] = m.F.y;
@@ -154,7 +154,7 @@ __device__ __forceinline__ P3 tree_transform(uint32_t code, const uint32_t* w, P
     case TC_ROTZ:   return rotz(p, as_f(w[2]), as_f(w[3]));
     case TC_ROTQ:   return rotq(p, as_f(w[2]), as_f(w[3]), as_f(w[4]), as_f(w[5]), as_f(w[6]), as_f(w[7]),
                                 as_f(w[8]), as_f(w[9]), as_f(w[10]));
-    default:        return ripeto(p, as_f(w[2]), as_f(w[3]), as_f(w[4]), as_f(w[5]));
+    default:        return ripeto(p, as_f(w[2]), as_f(w[3]), as_f(w[4]), as_f(w[5]), as_f(w[6]));
     }
 }
 
@@ -218,7 +218,7 @@ __device__ __forceinline__ float walk_dist(const TreeNode* tree, uint32_t root, 
                 node = w[2];
                 break;
             }
-            v = glata(st.acc[sp - 1], v, as_f(w[3]), code == TC_GLATA_KOMUNAJO);
+            v = glata(st.acc[sp - 1], v, as_f(w[3]), as_f(w[4]), code == TC_GLATA_KOMUNAJO);
             --sp;
         }
     }
@@ -280,8 +280,7 @@ __device__ __forceinline__ P3 walk_norm(const TreeNode* tree, uint32_t root, P3 
                 }
                 if (nary) { node = w[1 + pick]; continue; }
                 // glata_*: :362-374, :390-402
-                float q = (d0 - d1) / as_f(w[3]);
-                float h = ((code == TC_GLATA_KOMUNAJO) ? (1.f + q) : (1.f - q)) * .5f;
+                float h = glata_h(d0, d1, as_f(w[3]), as_f(w[4]), code == TC_GLATA_KOMUNAJO);
                 if (h > 1.f) { node = w[1]; continue; }
                 if (h < 0.f) { node = w[2]; continue; }
                 st.hdr[sp] = node;                 // phase 0: normal of child 0 pending

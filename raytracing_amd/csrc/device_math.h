@@ -12,11 +12,54 @@ struct P3 { float x, y, z; };
 // ---- scalar helpers (same arithmetic conventions as the CPU restatement) ---------------------
 
 __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// ---- correctly rounded sqrt and constant-divisor division in fewer instructions ---------------
+//
+// hipcc expands IEEE sqrtf into ~16 VALU instructions and '/' into ~12; a march step of
+// chair.sce holds three sqrt and one division, 40 % of its instructions.  The sequences
+// below give the SAME bits for every input, checked on the device rather than argued:
+//
+//  sqrt_exact: one Newton step on v_rsq_f32 with the residual taken by fma.  Compared with
+//    sqrtf for every float: identical for 2^-102 <= x <= FLT_MAX (tools/microbench/
+//    exact_math.hip; rm_selftest_math repeats the sweep through the C ABI, and rm_create
+//    refuses a device on which two binades of it fail).  Below 2^-100 (0, denormals: the
+//    residual underflows), and for inf, NaN and negatives, the wave falls back to sqrtf.
+//
+//  div_const(a, c, rc): Markstein's quotient from rc = RN(1/c): q = a*rc, q += (a - c*q)*rc,
+//    both corrections by fma.  Every operation scales exactly with a power of two while
+//    nothing leaves the normal range, so one binade of numerators proves a divisor for all
+//    2^-80 <= |a| < 2^80: rm_set_primitives runs that proof on the device for every divisor
+//    constant of a scene (senfina_ripeto's dot(a,a), glata's k) and hands rc = 0 for one
+//    that fails or lies outside [2^-20, 2^20]; rc = 0, or a numerator outside the range,
+//    takes IEEE division.
+__device__ __forceinline__ float sqrt_exact(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float g = x * r, h = 0.5f * r;
+    float y = __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(as_u(x) - 0x0d800000u >= 0x72000000u) != 0, 0)) {   // rare, whole wave
+        float xs = x;
+        asm volatile("; sqrt_exact: IEEE path" : "+v"(xs));      // keeps this a branch: the compiler would compute both and select
+        y = sqrtf(xs);
+    }
+    return y;
+}
+__device__ __forceinline__ float div_const(float a, float c, float rc) {
+    if (rc == 0.f) return a / c;                     // wave-uniform: rc is a scene constant
+    float q = a * rc;
+    q = __builtin_fmaf(__builtin_fmaf(-c, q, a), rc, q);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64((as_u(a) & 0x7fffffffu) - 0x17800000u >= 0x50000000u) != 0, 0)) {
+        float as = a;
+        asm volatile("; div_const: IEEE path" : "+v"(as));       // as in sqrt_exact
+        q = as / c;
+    }
+    return q;
+}
 __device__ __forceinline__ float min2(float a, float b) { return (b < a) ? b : a; }   // std::min
 __device__ __forceinline__ float max2(float a, float b) { return (a < b) ? b : a; }   // std::max
 // Include/cuda_defines.cuh:49-53
-__device__ __forceinline__ float length_3(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
-__device__ __forceinline__ float r_length_3(float x, float y, float z) { return 1.f / sqrtf(x * x + y * y + z * z); }
+__device__ __forceinline__ float length_3(float x, float y, float z) { return sqrt_exact(x * x + y * y + z * z); }
+__device__ __forceinline__ float r_length_3(float x, float y, float z) { return 1.f / sqrt_exact(x * x + y * y + z * z); }
 __device__ __forceinline__ float length_2(float x, float y) {
     return (float)sqrt((double)x * (double)x + (double)y * (double)y);
 }
@@ -49,8 +92,8 @@ __device__ __forceinline__ float ebeno_dist(P3 p, float nx, float ny, float nz) 
 }
 
 // smooth union / intersection (Source/cuda_kernels.cu:356-359, :384-387)
-__device__ __forceinline__ float glata(float d0, float d1, float k, bool komunajo) {
-    float q = (d0 - d1) / k;
+__device__ __forceinline__ float glata(float d0, float d1, float k, float rk, bool komunajo) {
+    float q = div_const(d0 - d1, k, rk);
     float h = (komunajo ? (1.f + q) : (1.f - q)) * .5f;
     float m = mixf(d0, d1, h);
     float e = k * h * (1.f - h);
@@ -70,8 +113,8 @@ __device__ __forceinline__ P3 rotq(P3 p, float xx, float xy, float xz, float yx,
               p.y + 2.f * (yx * p.x + yy * p.y + yz * p.z),
               p.z + 2.f * (zx * p.x + zy * p.y + zz * p.z)};
 }
-__device__ __forceinline__ P3 ripeto(P3 p, float ax, float ay, float az, float aa) {
-    float N = floorf(dot3(ax, ay, az, p.x, p.y, p.z) / aa + .5f);
+__device__ __forceinline__ P3 ripeto(P3 p, float ax, float ay, float az, float aa, float raa) {
+    float N = floorf(div_const(dot3(ax, ay, az, p.x, p.y, p.z), aa, raa) + .5f);
     return P3{p.x - N * ax, p.y - N * ay, p.z - N * az};
 }
 
@@ -111,8 +154,8 @@ __device__ __forceinline__ P3 glata_blend(P3 n0, P3 n1, float h) {
     return P3{mixf(d0 * n0.x, d1 * n1.x, h), mixf(d0 * n0.y, d1 * n1.y, h), mixf(d0 * n0.z, d1 * n1.z, h)};
 }
 // the blend parameter h of a glata_* node (:356, :384)
-__device__ __forceinline__ float glata_h(float d0, float d1, float k, bool komunajo) {
-    float q = (d0 - d1) / k;
+__device__ __forceinline__ float glata_h(float d0, float d1, float k, float rk, bool komunajo) {
+    float q = div_const(d0 - d1, k, rk);
     return (komunajo ? (1.f + q) : (1.f - q)) * .5f;
 }
 

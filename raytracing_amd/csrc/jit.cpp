@@ -51,7 +51,7 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
 
 }  // namespace
 
-std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen) {
+std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen, const DivisorSet* exact) {
     std::string s = "namespace rm {\n";
     const std::string FD = "__device__ __forceinline__ float ", FN = "__device__ __forceinline__ P3 ";
     // children carry higher indices than their parents (links point forward), so
@@ -93,8 +93,8 @@ std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned
             s += nn + "return " + fn('n', kid(0)) + "(movo(p, " + lit3(nd.f) + ")); }\n";
             break;
         case RM_TYPE_SENFINA_RIPETO: {
-            const float aa = nd.f[0] * nd.f[0] + nd.f[1] * nd.f[1] + nd.f[2] * nd.f[2];
-            const std::string t = "ripeto(p, " + lit3(nd.f) + ", " + lit(aa) + ")";
+            const float aa = ripeto_aa(nd);
+            const std::string t = "ripeto(p, " + lit3(nd.f) + ", " + lit(aa) + ", " + lit(divisor_reciprocal(exact, aa)) + ")";
             s += d + "return " + fn('d', kid(0)) + "(" + t + "); }\n";
             s += nn + "return " + fn('n', kid(0)) + "(" + t + "); }\n";
             break;
@@ -115,7 +115,8 @@ std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned
             break;
         }
         case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: {
-            const std::string kom = nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? "true" : "false", k = lit(nd.f[0]);
+            const std::string kom = nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? "true" : "false",
+                              k = lit(nd.f[0]) + ", " + lit(divisor_reciprocal(exact, nd.f[0]));
             const std::string d0 = fn('d', kid(0)) + "(p)", d1 = fn('d', kid(1)) + "(p)";
             s += d + "return glata(" + d0 + ", " + d1 + ", " + k + ", " + kom + "); }\n";
             s += nn + "float a = " + d0 + ", b = " + d1 + "; float h = glata_h(a, b, " + k + ", " + kom + "); " +

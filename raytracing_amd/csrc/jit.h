@@ -16,6 +16,7 @@
 
 #include "../../include/raymarching_amd.h"
 #include "kernel_params.h"
+#include "scene_build.h"
 
 namespace rm {
 
@@ -32,7 +33,7 @@ struct JitKernels {
 
 // HIP source of the d<i>/n<i> function pairs of every reachable node plus the
 // kernels built on them.  `seen[i]` marks reachable nodes (scene_build).
-std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen);
+std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen, const DivisorSet* exact = nullptr);
 
 // prelude (flattened device headers) + scene source: what hiprtc is given
 std::string jit_full_source(const std::string& scene_source);

@@ -72,6 +72,10 @@ hipError_t launch_eval_rays(const RenderParams& prm, const int* xy, uint32_t cou
 // raise the kernels' dynamic-LDS ceiling when a scene needs more than the 64 KiB default
 hipError_t configure_lds(size_t lds_bytes);
 hipError_t kernel_attributes(int* vgprs, int* scratch_bytes);
+// enumeration proofs of device_math.h's short sqrt / quotient sequences (mismatch counts in *bad)
+hipError_t launch_verify_sqrt(uint32_t first, unsigned long long count, unsigned long long* bad, hipStream_t stream);
+hipError_t launch_verify_div(const float* c, const float* rc, uint32_t n, uint32_t first, unsigned long long count,
+                             unsigned long long* bad, hipStream_t stream);
 #endif
 
 }  // namespace rm

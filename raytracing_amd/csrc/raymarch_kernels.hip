@@ -65,7 +65,51 @@ __global__ void eval_rays_kernel(const RenderParams prm, const int* __restrict__
     out[6 * i + 3] = d.x; out[6 * i + 4] = d.y; out[6 * i + 5] = d.z;
 }
 
+// =============================================================================
+// Proofs by enumeration for device_math.h's short sqrt and quotient sequences.
+// =============================================================================
+
+// sqrt_exact against IEEE sqrtf over `count` consecutive bit patterns from `first`
+__global__ void __launch_bounds__(256)
+verify_sqrt_kernel(uint32_t first, unsigned long long count, unsigned long long* bad) {
+    unsigned long long mine = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float x = as_f(first + (uint32_t)i);
+        const float want = sqrtf(x), got = sqrt_exact(x);
+        if (as_u(want) != as_u(got) && !(want != want && got != got)) ++mine;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+// div_const against IEEE division.  blockIdx.y picks the divisor; numerators are `count`
+// consecutive bit patterns from `first` (one binade, [1,2), proves a divisor: device_math.h)
+__global__ void __launch_bounds__(256)
+verify_div_kernel(const float* __restrict__ c, const float* __restrict__ rc, uint32_t first, unsigned long long count,
+                  unsigned long long* bad) {
+    const float cc = c[blockIdx.y], rr = rc[blockIdx.y];
+    unsigned long long mine = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float a = as_f(first + (uint32_t)i);
+        const float want = a / cc, got = div_const(a, cc, rr);
+        if (as_u(want) != as_u(got) && !(want != want && got != got)) ++mine;
+    }
+    if (mine) atomicAdd(bad + blockIdx.y, mine);
+}
+
 // ---- launchers (called from capi.cpp) -----------------------------------------
+
+hipError_t launch_verify_sqrt(uint32_t first, unsigned long long count, unsigned long long* bad, hipStream_t stream) {
+    hipLaunchKernelGGL(verify_sqrt_kernel, dim3(2048), dim3(256), 0, stream, first, count, bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_verify_div(const float* c, const float* rc, uint32_t n, uint32_t first, unsigned long long count,
+                             unsigned long long* bad, hipStream_t stream) {
+    hipLaunchKernelGGL(verify_div_kernel, dim3(count > (1u << 24) ? 2048 : 64, n), dim3(256), 0, stream, c, rc, first, count, bad);
+    return hipGetLastError();
+}
 
 hipError_t launch_render(const RenderParams& prm, unsigned blocks, size_t lds_bytes, hipStream_t stream) {
     hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(RM_BLOCK_THREADS), lds_bytes, stream, prm);

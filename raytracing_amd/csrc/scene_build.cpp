@@ -121,6 +121,7 @@ enum Src { SRC_P = 0, SRC_F = 1 };
 struct Flattener {
     const rm_node* nodes;
     size_t n;
+    const DivisorSet* exact = nullptr;
     std::vector<Slot> prog;
     std::vector<unsigned char> seen;
     uint32_t sp = 0, max_sp = 0;     // LDS stack depth in dwords
@@ -272,7 +273,8 @@ struct Flattener {
         case RM_TYPE_SENFINA_RIPETO: {
             Slot& s = emit(OP_RIPETO, sflag);
             s.w[1] = fbits(nd.f[0]); s.w[2] = fbits(nd.f[1]); s.w[3] = fbits(nd.f[2]);
-            s.w[4] = fbits(nd.f[0] * nd.f[0] + nd.f[1] * nd.f[1] + nd.f[2] * nd.f[2]);
+            s.w[4] = fbits(ripeto_aa(nd));
+            s.w[5] = fbits(divisor_reciprocal(exact, ripeto_aa(nd)));
             last_xf = static_cast<long>(prog.size()) - 1;
             eval(child(idx, 0), SRC_P);
             break;
@@ -298,6 +300,7 @@ struct Flattener {
             Slot& s = emit(in_b ? OP_GLATA_R : OP_GLATA,
                            (nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? F_NEG : 0) | (slot << F_SLOT_SHIFT));
             s.w[1] = fbits(nd.f[0]);
+            s.w[2] = fbits(divisor_reciprocal(exact, nd.f[0]));
             pop_release(in_b);
             f_live = was_live;
             leave_frame(saved);
@@ -376,8 +379,11 @@ struct Flattener {
             case RM_TYPE_KOMUNAJO_2: case RM_TYPE_KOMUNAJO_3: case RM_TYPE_KOMUNAJO_4:
                 code = TC_KOMUNAJO; for (int k = 0; k < na; ++k) t.w[1 + k] = kid(k); break;
             case RM_TYPE_KOMPLEMENTO: code = TC_KOMPLEMENTO; t.w[1] = kid(0); break;
-            case RM_TYPE_GLATA_KUNIGAJO_2: code = TC_GLATA_KUNIGAJO; t.w[1] = kid(0); t.w[2] = kid(1); put(3, 1); break;
-            case RM_TYPE_GLATA_KOMUNAJO_2: code = TC_GLATA_KOMUNAJO; t.w[1] = kid(0); t.w[2] = kid(1); put(3, 1); break;
+            case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2:
+                code = nd.type == RM_TYPE_GLATA_KUNIGAJO_2 ? TC_GLATA_KUNIGAJO : TC_GLATA_KOMUNAJO;
+                t.w[1] = kid(0); t.w[2] = kid(1); put(3, 1);
+                t.w[4] = fbits(divisor_reciprocal(exact, nd.f[0]));
+                break;
             case RM_TYPE_MOVO: code = TC_MOVO; t.w[1] = kid(0); put(2, 3); break;
             case RM_TYPE_ROTACIOX: code = TC_ROTX; t.w[1] = kid(0); put(2, 2); break;
             case RM_TYPE_ROTACIOY: code = TC_ROTY; t.w[1] = kid(0); put(2, 2); break;
@@ -390,7 +396,8 @@ struct Flattener {
             }
             case RM_TYPE_SENFINA_RIPETO:
                 code = TC_RIPETO; t.w[1] = kid(0); put(2, 3);
-                t.w[5] = fbits(nd.f[0] * nd.f[0] + nd.f[1] * nd.f[1] + nd.f[2] * nd.f[2]);
+                t.w[5] = fbits(ripeto_aa(nd));
+                t.w[6] = fbits(divisor_reciprocal(exact, ripeto_aa(nd)));
                 break;
             default: break;
             }
@@ -401,11 +408,34 @@ struct Flattener {
 
 }  // namespace
 
-int build_scene(const rm_node* nodes, size_t n, SceneBuild& out) {
+// Source/cuda_kernels.cu:578: dot(a, a), summed left to right
+float ripeto_aa(const rm_node& nd) { return nd.f[0] * nd.f[0] + nd.f[1] * nd.f[1] + nd.f[2] * nd.f[2]; }
+
+std::vector<float> scene_divisors(const rm_node* nodes, size_t n) {
+    std::set<uint32_t> have;
+    std::vector<float> out;
+    for (size_t i = 0; i < n; ++i) {
+        float c;
+        if (nodes[i].type == RM_TYPE_SENFINA_RIPETO) c = ripeto_aa(nodes[i]);
+        else if (nodes[i].type == RM_TYPE_GLATA_KUNIGAJO_2 || nodes[i].type == RM_TYPE_GLATA_KOMUNAJO_2) c = nodes[i].f[0];
+        else continue;
+        uint32_t u; std::memcpy(&u, &c, 4);
+        if (have.insert(u).second) out.push_back(c);
+    }
+    return out;
+}
+
+float divisor_reciprocal(const DivisorSet* exact, float c) {
+    uint32_t u; std::memcpy(&u, &c, 4);
+    if (!exact || !exact->count(u)) return 0.f;
+    return 1.0f / c;                     // correctly rounded: IEEE division on the host
+}
+
+int build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSet* exact) {
     if (!nodes || n == 0) return RM_ERR_INVALID_ARG;
     if (n > RM_MAX_NODES) return RM_ERR_TOO_LARGE;
     Flattener fl;
-    fl.nodes = nodes; fl.n = n;
+    fl.nodes = nodes; fl.n = n; fl.exact = exact;
     fl.seen.assign(n, 0);
     fl.eval(0, SRC_F);
     if (fl.err) return fl.err;

@@ -2,6 +2,7 @@
 // flattener that produces the two device forms declared in scene_program.h.
 #pragma once
 #include <cstddef>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -33,8 +34,17 @@ void encode_sce(const rm_node* nodes, size_t n, std::vector<unsigned char>& byte
 int  load_sce(const char* path, std::vector<rm_node>& out);
 int  save_sce(const char* path, const rm_node* nodes, size_t n);
 
+// Divisor constants (float bit patterns) for which the device has proved the short
+// quotient sequence exact (device_math.h div_const; capi.cpp verify_divisors).
+typedef std::set<uint32_t> DivisorSet;
+// The divisor constants of a node table: dot(a,a) of every senfina_ripeto, k of every glata_*.
+std::vector<float> scene_divisors(const rm_node* nodes, size_t n);
+float ripeto_aa(const rm_node& nd);                  // dot(a,a) in the reference's operation order
+// RN(1/c) if c is in `exact`, else 0 (= use IEEE division)
+float divisor_reciprocal(const DivisorSet* exact, float c);
+
 // Validate and flatten.  Returns an rm_status.
-int  build_scene(const rm_node* nodes, size_t n, SceneBuild& out);
+int  build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSet* exact = nullptr);
 
 // Human-readable listing of a distance program (tests).
 std::string disassemble(const std::vector<Slot>& program);

@@ -36,14 +36,14 @@ enum TreeCode : uint32_t {
     TC_KUNIGAJO,      // w1..w[arity] children      (arity in bits 8..15 of w0)
     TC_KOMUNAJO,      // w1..w[arity] children
     TC_KOMPLEMENTO,   // w1 child
-    TC_GLATA_KUNIGAJO,// w1 w2 children, w3 k
-    TC_GLATA_KOMUNAJO,// w1 w2 children, w3 k
+    TC_GLATA_KUNIGAJO,// w1 w2 children, w3 k, w4 RN(1/k) or 0 (device_math.h div_const)
+    TC_GLATA_KOMUNAJO,// w1 w2 children, w3 k, w4 RN(1/k) or 0
     TC_MOVO,          // w1 child, w2-4 t
     TC_ROTX,          // w1 child, w2 cos, w3 sin
     TC_ROTY,
     TC_ROTZ,
     TC_ROTQ,          // w1 child, w2-10 Q (xx xy xz yx yy yz zx zy zz)
-    TC_RIPETO         // w1 child, w2-4 a, w5 dot(a,a)
+    TC_RIPETO         // w1 child, w2-4 a, w5 dot(a,a), w6 RN(1/dot(a,a)) or 0
 };
 
 struct alignas(16) TreeNode { uint32_t w[12]; };
@@ -68,7 +68,7 @@ enum Op : uint32_t {
     OP_ROTZ,
     OP_ROTQ_XY,   // rows x,y of P = p + 2 (Q p) into temporaries: w1-6 = xx xy xz yx yy yz
     OP_ROTQ_Z,    // row z, then P = (tx, ty, z): w1-3 = zx zy zz   (always follows OP_ROTQ_XY, same src)
-    OP_RIPETO,    // w1-3 a, w4 dot(a,a)
+    OP_RIPETO,    // w1-3 a, w4 dot(a,a), w5 RN(1/dot(a,a)) or 0 (device_math.h div_const)
     OP_SETF,      // F = P
     // primitives: v = prim(src - t) ; v = NEG ? -v : v ; A = combine(A, v)
     OP_SFERO,     // w1-3 t, w4 r
@@ -81,7 +81,7 @@ enum Op : uint32_t {
     OP_PUSHA,     // stack[slot] = A ; A = +inf
     OP_POPC,      // A = combine(stack[slot], A)
     OP_NEG,       // A = -A
-    OP_GLATA_R,   // A = smooth(B, A, k)            w1 k, NEG bit: 0 kunigajo, 1 komunajo
+    OP_GLATA_R,   // A = smooth(B, A, k)            w1 k, w2 RN(1/k) or 0, NEG bit: 0 kunigajo, 1 komunajo
     OP_GLATA,     // A = smooth(stack[slot], A, k)
     // frames
     OP_PUSHF,     // stack[slot..slot+2] = F ; F = P

@@ -282,3 +282,28 @@ def test_many_frames_infinity(stock_scenes):
         rm.set_boost_age(0xffffffff)
         rm.process()
         assert np.array_equal(rm.read_pixels(), ref["rgba"])
+
+
+def test_short_sqrt_and_quotient_are_ieee_for_every_input():
+    """device_math.h sqrt_exact / div_const against IEEE sqrtf and '/' on the device, all 2^32
+    bit patterns (argument; numerator per divisor): zero mismatches, NaNs compared as equal."""
+    divisors = [260000.0, 10000.0, 54.0, 2.5, 1.5, 0.7, 3.0, 1e-3, 123456.789, 7.0, 0.1, -2.0, 1.0, 2.0 ** -20, 2.0 ** 20,
+                np.float32(np.nextafter(np.float32(2.0), np.float32(0.0)))]       # the last one: mantissa all ones
+    with api.Raymarching(8, 8) as rm:
+        sq, dv = rm.selftest_math(divisors)
+    assert sq == 0
+    assert dv == [0] * len(divisors)
+
+
+def test_divisors_are_proved_per_scene(stock_scenes):
+    info = O.default_info(1, 0)
+    ref = O.render(stock_scenes["infinity"], 160, 100, info, threads=min(16, os.cpu_count() or 4))
+    for short, path in [(True, "jit"), (False, "jit"), (True, "program"), (False, "program")]:
+        with api.Raymarching(160, 100) as rm:
+            rm.set_short_math(short)
+            rm.set_jit(PATHS[path][0])
+            rm.set_nodes(stock_scenes["infinity"])
+            assert rm.scene_stats()["exact_divisors"] == (1 if short else 0)     # dot(a,a) = 10000 three times
+            rm.set_info(info)
+            rm.process()
+            assert np.array_equal(rm.read_pixels(), ref["rgba"])

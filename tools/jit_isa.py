@@ -17,7 +17,7 @@ if name == "csg1024":
     nodes = scenes.csg1024()
 else:
     nodes = api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", name + ".sce"))
-rc, src = api.jit_check(nodes, want_source=True)
+rc, src = api.jit_check(nodes, want_source=True, assume_exact_divisors=True)
 assert rc == 0, rc
 bundle = open(os.path.join(ROOT, "raytracing_amd", "csrc", "jit_bundle.inc")).read()
 prelude = bundle[bundle.index('R"RMJIT(') + 8: bundle.rindex(')RMJIT"')]
