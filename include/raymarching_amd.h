@@ -176,6 +176,10 @@ int rm_set_norm_batch(rm_ctx* ctx, int lanes);
 int rm_selftest_math(rm_ctx* ctx, const float* divisors, size_t n, unsigned long long* sqrt_mismatches,
                      unsigned long long* div_mismatches);
 
+/* enable = 0: scenes uploaded from now on are flattened without bounding-sphere
+ * tests in front of the sub-trees of unions (diagnostic; identical results). */
+int rm_set_culling(rm_ctx* ctx, int enable);
+
 /* enable = 0: scenes uploaded from now on divide by their constants with IEEE
  * division only (diagnostic; identical results). */
 int rm_set_short_math(rm_ctx* ctx, int enable);

@@ -28,7 +28,7 @@ EXPORTS = [
     "rm_local_rows", "rm_enable_hit_mask", "rm_process", "rm_process_async", "rm_synchronize",
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
-    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_jit", "rm_jit_log", "rm_jit_check",
+    "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
             "rm_set_heavy_first": [vp, i32],
             "rm_selftest_math": [vp, vp, sz, C.POINTER(C.c_ulonglong), vp],
             "rm_set_short_math": [vp, i32],
+            "rm_set_culling": [vp, i32],
             "rm_eval_points": [vp, i32, sz, vp, sz, vp, vp],
             "rm_eval_rays": [vp, vp, sz, vp],
             "rm_debug_wave_stats": [vp, vp, sz, C.POINTER(sz)],
@@ -242,6 +243,9 @@ class Raymarching:
         _check(lib().rm_selftest_math(self._ctx, _ptr(d) if d.size else None, d.size, C.byref(sq), _ptr(bad)),
                "rm_selftest_math")
         return sq.value, [int(x) for x in bad[:d.size]]
+
+    def set_culling(self, enable=True):
+        _check(lib().rm_set_culling(self._ctx, 1 if enable else 0), "rm_set_culling")
 
     def set_short_math(self, enable=True):
         _check(lib().rm_set_short_math(self._ctx, 1 if enable else 0), "rm_set_short_math")

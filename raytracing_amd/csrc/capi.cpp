@@ -52,6 +52,7 @@ struct rm_ctx {
     bool feedback = true;             // frames file their tiles by cost for the next frame
     bool history = false;             // the previous frame did, with the same tile numbering
     uint32_t boost_age = 48;
+    bool cull = true;                 // bounding-sphere tests in union chains (scene_build.cpp)
     bool short_math = true;           // scenes may use div_const for divisors the device has proved
     uint32_t exact_divisors = 0;      // how many of the current scene's divisor constants were
     int cus = 1, blocks_per_cu = 1;   // of the device / of the ahead-of-time kernel at lds_bytes
@@ -200,7 +201,7 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     rm::DivisorSet exact;
     if (c->short_math) HIP_TRY(exact_divisors(c, nodes, n, exact));
     rm::SceneBuild built;
-    int rc = rm::build_scene(nodes, n, built, &exact);
+    int rc = rm::build_scene(nodes, n, built, &exact, c->cull);
     if (rc != RM_OK) return rc;
     c->exact_divisors = static_cast<uint32_t>(exact.size());
     const size_t lds = built.tree.size() * sizeof(rm::TreeNode) +
@@ -572,6 +573,12 @@ int rm_selftest_math(rm_ctx* c, const float* divisors, size_t n, unsigned long l
     std::vector<unsigned long long> bad;
     HIP_TRY(check_divisors(c, cs, 0u, 1ull << 32, bad));
     for (size_t i = 0; i < n; ++i) div_mismatches[i] = bad[i];
+    return RM_OK;
+}
+
+int rm_set_culling(rm_ctx* c, int enable) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    c->cull = enable != 0;
     return RM_OK;
 }
 

@@ -46,7 +46,7 @@ __device__ __forceinline__ float chain(float a, float v, float sel) { return __b
 
 // Executes one slot.  Returns the number of slots to skip after it (portanta_sfero only).
 template <bool SRC_F>
-__device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* stack) {
+__device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* stack, bool active) {
     const uint32_t w0 = w[0], op = w0 & 0xff, slot = w0 >> F_SLOT_SHIFT;
     const P3 S = SRC_F ? m.F : m.P;
     const float f1 = as_f(w[1]), f2 = as_f(w[2]), f3 = as_f(w[3]), f4 = as_f(w[4]),
@@ -101,6 +101,13 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
         if (__builtin_amdgcn_ballot_w64(d <= RM_MIN_DIST) == 0) skip = w[5];
         break;
     }
+    case OP_CULL: {                // scene_program.h; lanes that do not march have no say
+        const float dx = S.x - f1, dy = S.y - f2, dz = S.z - f3;
+        const float s2 = dx * dx + dy * dy + dz * dz, T = m.A + f4;
+        const bool far = T < 0.f || s2 > T * T * 1.001953125f;      // false for NaN: never culls
+        if (__builtin_amdgcn_ballot_w64(active && !far) == 0) skip = w[5];
+        break;
+    }
     case OP_PORTANTA_END: {
         float d = stack[slot * RM_BLOCK_THREADS];
         m.A = (d <= RM_MIN_DIST) ? m.A : d;
@@ -112,7 +119,7 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
     return skip;
 }
 
-__device__ __forceinline__ float run_program(const Slot* __restrict__ prog, P3 E, float* stack) {
+__device__ __forceinline__ float run_program(const Slot* __restrict__ prog, P3 E, float* stack, bool active) {
     Machine m;
     m.F = E; m.P = E;
     m.A = __builtin_inff(); m.B = 0.f; m.tx = 0.f; m.ty = 0.f;
@@ -121,7 +128,7 @@ __device__ __forceinline__ float run_program(const Slot* __restrict__ prog, P3 E
     await_slot(cur);
     while ((cur[0] & 0xff) != OP_END) {
         u32x8 nxt = fetch_slot(prog, (pc + 1) * (uint32_t)sizeof(Slot));      // in flight while `cur` executes
-        const uint32_t skip = (cur[0] & F_SRC_F) ? exec_slot<true>(m, cur, stack) : exec_slot<false>(m, cur, stack);
+        const uint32_t skip = (cur[0] & F_SRC_F) ? exec_slot<true>(m, cur, stack, active) : exec_slot<false>(m, cur, stack, active);
         pc += 1;
         if (skip) {                     // rare: the prefetched slot is not the next one
             await_slot(nxt);
@@ -363,9 +370,9 @@ struct InterpScene {
         evaluator = prm.evaluator;
         stage_tree(prm.tree, prm.n_nodes, lds);
     }
-    // every lane of the wave must call this together
-    __device__ __forceinline__ float dist(P3 p, Scratch& st) {
-        return evaluator == 0 ? run_program(program, p, stack) : walk_dist(tree, 0, p, st, 0);
+    // every lane of the wave must call this together; `active`: this lane needs the value
+    __device__ __forceinline__ float dist(P3 p, Scratch& st, bool active) {
+        return evaluator == 0 ? run_program(program, p, stack, active) : walk_dist(tree, 0, p, st, 0);
     }
     __device__ __forceinline__ P3 norm(P3 p, Scratch& st) { return walk_norm(tree, 0, p, st); }
 };

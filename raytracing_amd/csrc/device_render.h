@@ -208,7 +208,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             if (amask != 0) {
                 ++st_evals;
                 // DIST(root, pos) for the whole wave (:627 and :661 share this)
-                float d = scene.dist(pos, scratch);
+                float d = scene.dist(pos, scratch, active);
                 if (active) {
                     cd = d;
                     if (mode == M_PRIMARY) {

@@ -150,7 +150,7 @@ std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned
 struct JitScene {
     struct Scratch {};
     __device__ __forceinline__ void init(const RenderParams&) {}
-    __device__ __forceinline__ float dist(P3 p, Scratch&) { return d0(p); }
+    __device__ __forceinline__ float dist(P3 p, Scratch&, bool) { return d0(p); }
     __device__ __forceinline__ P3 norm(P3 p, Scratch&) { return n0(p); }
 };
 }  // namespace rm

@@ -44,7 +44,7 @@ eval_points_kernel(const RenderParams prm, int which, uint32_t idx, const float*
     if (live) p = P3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     WalkStack st;
     float d;
-    if (which == 0) d = run_program(prm.program, p, stack);      // wave-uniform: all lanes run it
+    if (which == 0) d = run_program(prm.program, p, stack, live);      // wave-uniform: all lanes run it
     else            d = live ? walk_dist(tree, idx, p, st, 0) : 0.f;
     if (live) {
         dist_out[i] = d;

@@ -7,6 +7,8 @@
 #include "scene_build.h"
 
 #include <cstdio>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace rm {
@@ -122,6 +124,7 @@ struct Flattener {
     const rm_node* nodes;
     size_t n;
     const DivisorSet* exact = nullptr;
+    bool cull = true;                // emit OP_CULL in union chains
     std::vector<Slot> prog;
     std::vector<unsigned char> seen;
     uint32_t sp = 0, max_sp = 0;     // LDS stack depth in dwords
@@ -311,8 +314,14 @@ struct Flattener {
             bool is_min = nd.type == RM_TYPE_KUNIGAJO_2 || nd.type == RM_TYPE_KUNIGAJO_3 || nd.type == RM_TYPE_KUNIGAJO_4;
             long saved = enter_frame(src);
             bool was_live = f_live; f_live = true;
-            eval(child(idx, 0), SRC_F);
-            for (int k = 1; k < na; ++k) accum(child(idx, k), is_min ? COMB_MIN : COMB_MAX);
+            if (is_min && cull) {
+                std::vector<Item> items;
+                gather(idx, items);
+                emit_union(items);
+            } else {
+                eval(child(idx, 0), SRC_F);
+                for (int k = 1; k < na; ++k) accum(child(idx, k), is_min ? COMB_MIN : COMB_MAX);
+            }
             f_live = was_live;
             leave_frame(saved);
             break;
@@ -321,11 +330,200 @@ struct Flattener {
         --depth;
     }
 
+    // ---- bounding spheres (for OP_CULL) ------------------------------------------------
+    // A sphere (centre c, radius r, in the coordinates of the node's input point) with
+    // DIST(node, p) >= |p - c| - r for every p, in exact arithmetic; `reach` bounds the
+    // magnitude of every intermediate coordinate offset below the node (the scale of the
+    // rounding errors of its evaluation); `leaves` counts primitive slots.
+    struct Bound { bool ok = false; double c[3] = {0, 0, 0}, r = 0, reach = 0; uint32_t leaves = 0; };
+
+    static Bound enclose(const Bound& a, const Bound& b) {     // smallest sphere around two spheres
+        Bound o; o.ok = true;
+        double d[3] = { b.c[0] - a.c[0], b.c[1] - a.c[1], b.c[2] - a.c[2] };
+        double dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (dist + b.r <= a.r) { o = a; }
+        else if (dist + a.r <= b.r) { o = b; }
+        else {
+            o.r = (dist + a.r + b.r) / 2;
+            double k = (o.r - a.r) / dist;
+            for (int i = 0; i < 3; ++i) o.c[i] = a.c[i] + d[i] * k;
+        }
+        o.reach = a.reach > b.reach ? a.reach : b.reach;
+        o.leaves = a.leaves + b.leaves;
+        return o;
+    }
+
+    Bound bound_of(size_t idx, uint32_t guard = 0) {
+        Bound none;
+        if (idx >= n || guard > kMaxTreeDepth) return none;
+        const rm_node& nd = nodes[idx];
+        auto kid = [&](int k) -> size_t { int32_t o = nd.o[k]; return o > 0 ? idx + static_cast<size_t>(o) : n; };
+        auto pos = [](float v) { return v > 0 ? static_cast<double>(v) : 0.0; };
+        Bound b;
+        switch (nd.type) {
+        case RM_TYPE_SFERO: b.ok = true; b.r = pos(nd.f[0]); b.leaves = 1; break;
+        case RM_TYPE_KUBO:
+            b.ok = true; b.leaves = 1;
+            b.r = std::sqrt(pos(nd.f[0]) * pos(nd.f[0]) + pos(nd.f[1]) * pos(nd.f[1]) + pos(nd.f[2]) * pos(nd.f[2]));
+            break;
+        case RM_TYPE_CILINDRO:
+            b.ok = true; b.leaves = 1;
+            b.r = std::sqrt(pos(nd.f[0]) * pos(nd.f[0]) + pos(nd.f[1]) * pos(nd.f[1]));
+            break;
+        case RM_TYPE_MOVO: {                       // child sees p - t
+            b = bound_of(kid(0), guard + 1);
+            if (!b.ok) return none;
+            double tl = 0;
+            for (int i = 0; i < 3; ++i) { b.c[i] += nd.f[i]; tl += static_cast<double>(nd.f[i]) * nd.f[i]; }
+            b.reach += std::sqrt(tl);
+            break;
+        }
+        case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY: case RM_TYPE_ROTACIOZ: case RM_TYPE_ROTACIOQ: {
+            // child sees M p: the centre goes back through M^-1 = M^T, if M is a rotation
+            double M[9];
+            if (nd.type == RM_TYPE_ROTACIOQ) {
+                float Q[9]; build_q(nd, Q);
+                for (int i = 0; i < 9; ++i) M[i] = 2.0 * Q[i] + ((i % 4 == 0) ? 1.0 : 0.0);
+            } else {
+                const double c = nd.f[0], s_ = nd.f[1];
+                const double X[9] = {1, 0, 0, 0, c, s_, 0, -s_, c}, Y[9] = {c, 0, -s_, 0, 1, 0, s_, 0, c}, Z[9] = {c, s_, 0, -s_, c, 0, 0, 0, 1};
+                const double* src = nd.type == RM_TYPE_ROTACIOX ? X : nd.type == RM_TYPE_ROTACIOY ? Y : Z;
+                for (int i = 0; i < 9; ++i) M[i] = src[i];
+            }
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double dot = 0;
+                    for (int k = 0; k < 3; ++k) dot += M[3 * i + k] * M[3 * j + k];
+                    if (!(std::fabs(dot - (i == j ? 1.0 : 0.0)) < 1e-5)) return none;     // not a rotation (or NaN)
+                }
+            b = bound_of(kid(0), guard + 1);
+            if (!b.ok) return none;
+            double c0[3] = { b.c[0], b.c[1], b.c[2] };
+            for (int j = 0; j < 3; ++j) b.c[j] = M[j] * c0[0] + M[3 + j] * c0[1] + M[6 + j] * c0[2];
+            b.r = b.r * (1 + 1e-4) + 1e-6;
+            break;
+        }
+        case RM_TYPE_KUNIGAJO_2: case RM_TYPE_KUNIGAJO_3: case RM_TYPE_KUNIGAJO_4: {
+            const int na = node_arity(nd.type);
+            b = bound_of(kid(0), guard + 1);
+            for (int k = 1; k < na && b.ok; ++k) {
+                Bound o = bound_of(kid(k), guard + 1);
+                if (!o.ok) return none;
+                b = enclose(b, o);
+            }
+            if (!b.ok) return none;
+            break;
+        }
+        case RM_TYPE_KOMUNAJO_2: case RM_TYPE_KOMUNAJO_3: case RM_TYPE_KOMUNAJO_4: {
+            // max(d_i) >= every d_i: any child's sphere will do, take the smallest
+            const int na = node_arity(nd.type);
+            double reach = 0; uint32_t leaves = 0;
+            for (int k = 0; k < na; ++k) {
+                Bound o = bound_of(kid(k), guard + 1);
+                leaves += o.ok ? o.leaves : 1;
+                if (o.reach > reach) reach = o.reach;
+                if (o.ok && (!b.ok || o.r < b.r)) b = o;
+            }
+            if (!b.ok) return none;
+            b.reach = reach; b.leaves = leaves;
+            break;
+        }
+        default: return none;                      // unbounded or not handled: never culled
+        }
+        for (int i = 0; i < 3; ++i) if (!std::isfinite(b.c[i])) return none;
+        if (!std::isfinite(b.r) || !std::isfinite(b.reach)) return none;
+        return b;
+    }
+
+    // Emits OP_CULL for the sub-tree `idx` about to be merged into a min chain; returns the
+    // slot to patch with the skip count, or -1.
+    long begin_cull(size_t idx, uint32_t comb) {
+        if (comb != COMB_MIN || !cull) return -1;
+        Bound b = bound_of(idx);
+        if (!b.ok || b.leaves < 2) return -1;
+        return emit_cull(b);
+    }
+    long emit_cull(const Bound& b) {
+        const double cl = std::sqrt(b.c[0] * b.c[0] + b.c[1] * b.c[1] + b.c[2] * b.c[2]);
+        // the device compares |F - c|^2 with (A + w4)^2 (1 + 2^-9): a relative margin of 2^-10 on
+        // the distance plus this absolute one, against rounding errors of a few 2^-23 of the same scale
+        const double k = b.r * (1 + 1e-4) + (b.r + cl + b.reach + 1.0) / 1024.0;
+        Slot& s = emit(OP_CULL, F_SRC_F);
+        s.w[1] = fbits(static_cast<float>(b.c[0])); s.w[2] = fbits(static_cast<float>(b.c[1])); s.w[3] = fbits(static_cast<float>(b.c[2]));
+        s.w[4] = fbits(static_cast<float>(k) * 1.0001f + 1e-6f);
+        return static_cast<long>(prog.size()) - 1;
+    }
+    void end_cull(long at) {
+        if (at >= 0) prog[static_cast<size_t>(at)].w[5] = static_cast<uint32_t>(prog.size() - (static_cast<size_t>(at) + 1));
+    }
+
+    // ---- unions as bounding-volume hierarchies -------------------------------------------
+    // min is exact, commutative and associative, so the members of a union chain may be
+    // evaluated in any order and grouping (only the sign of a zero can differ).
+    // The chain is regrouped by position: a top-down median split over the members'
+    // bounding spheres, an OP_CULL in front of every group.
+    struct Item { size_t idx; uint32_t depth; Bound b; };
+    static bool is_union(uint32_t ty) { return ty == RM_TYPE_KUNIGAJO_2 || ty == RM_TYPE_KUNIGAJO_3 || ty == RM_TYPE_KUNIGAJO_4; }
+
+    // members of the chain rooted at union node `idx` (already entered with descend())
+    void gather(size_t idx, std::vector<Item>& items) {
+        const int na = node_arity(nodes[idx].type);
+        for (int k = 0; k < na && !err; ++k) {
+            const size_t c = child(idx, k);
+            if (err || !check_chain(c)) return;
+            if (is_union(nodes[c].type)) {
+                if (!descend(c)) return;
+                gather(c, items);
+                --depth;
+            } else {
+                Item it; it.idx = c; it.depth = depth; it.b = bound_of(c);
+                items.push_back(it);
+            }
+        }
+    }
+    void emit_item(const Item& it) {
+        const uint32_t keep = depth;
+        depth = it.depth;
+        accum(it.idx, COMB_MIN);
+        depth = keep;
+    }
+    void emit_group(std::vector<Item>& v, size_t lo, size_t hi, bool root) {
+        if (err) return;
+        if (hi - lo <= 2) { for (size_t i = lo; i < hi; ++i) emit_item(v[i]); return; }
+        Bound e = v[lo].b;
+        double mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) mn[a] = mx[a] = v[lo].b.c[a];
+        for (size_t i = lo + 1; i < hi; ++i) {
+            e = enclose(e, v[i].b);
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], v[i].b.c[a]); mx[a] = std::max(mx[a], v[i].b.c[a]); }
+        }
+        const long at = root ? -1 : emit_cull(e);
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+        const size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(v.begin() + static_cast<long>(lo), v.begin() + static_cast<long>(mid), v.begin() + static_cast<long>(hi),
+                         [axis](const Item& x, const Item& y) { return x.b.c[axis] < y.b.c[axis] || (x.b.c[axis] == y.b.c[axis] && x.idx < y.idx); });
+        emit_group(v, lo, mid, false);
+        emit_group(v, mid, hi, false);
+        end_cull(at);
+    }
+    // A = min(A, every member); A is +inf on entry of a chain, so the first member sets it
+    void emit_union(std::vector<Item>& items) {
+        std::vector<Item> bounded;
+        for (const Item& it : items) { if (it.b.ok) bounded.push_back(it); else emit_item(it); }
+        emit_group(bounded, 0, bounded.size(), true);
+    }
+
     // A = comb(A, DIST(node idx, F))
     void accum(size_t idx, uint32_t comb) {
         if (err) return;
         if (!check_chain(idx)) return;
         if (try_prim(idx, SRC_F, comb)) return;
+        const long cull_at = begin_cull(idx, comb);
+        accum_body(idx, comb);
+        end_cull(cull_at);
+    }
+    void accum_body(size_t idx, uint32_t comb) {
         const uint32_t ty = idx < n ? nodes[idx].type : 0;
         const bool same_kind =
             (comb == COMB_MIN && (ty == RM_TYPE_KUNIGAJO_2 || ty == RM_TYPE_KUNIGAJO_3 || ty == RM_TYPE_KUNIGAJO_4)) ||
@@ -431,11 +629,11 @@ float divisor_reciprocal(const DivisorSet* exact, float c) {
     return 1.0f / c;                     // correctly rounded: IEEE division on the host
 }
 
-int build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSet* exact) {
+int build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSet* exact, bool cull) {
     if (!nodes || n == 0) return RM_ERR_INVALID_ARG;
     if (n > RM_MAX_NODES) return RM_ERR_TOO_LARGE;
     Flattener fl;
-    fl.nodes = nodes; fl.n = n; fl.exact = exact;
+    fl.nodes = nodes; fl.n = n; fl.exact = exact; fl.cull = cull;
     fl.seen.assign(n, 0);
     fl.eval(0, SRC_F);
     if (fl.err) return fl.err;
@@ -457,7 +655,7 @@ std::string disassemble(const std::vector<Slot>& program) {
         "END", "MOVO", "ROTX", "ROTY", "ROTZ", "ROTQ_XY", "ROTQ_Z", "RIPETO", "SETF",
         "SFERO", "KUBO", "CILINDRO", "EBENO",
         "PUSHA_R", "POPC_R", "PUSHA", "POPC", "NEG", "GLATA_R", "GLATA",
-        "PUSHF", "POPF", "PORTANTA", "PORTANTA_END" };
+        "PUSHF", "POPF", "PORTANTA", "PORTANTA_END", "CULL" };
     static const char* combs[4] = { "-", "min", "max", "?" };
     std::string s;
     char line[256];

@@ -44,7 +44,8 @@ float ripeto_aa(const rm_node& nd);                  // dot(a,a) in the referenc
 float divisor_reciprocal(const DivisorSet* exact, float c);
 
 // Validate and flatten.  Returns an rm_status.
-int  build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSet* exact = nullptr);
+// cull: put bounding-sphere tests (OP_CULL) in front of the sub-trees of union chains
+int  build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSet* exact = nullptr, bool cull = true);
 
 // Human-readable listing of a distance program (tests).
 std::string disassemble(const std::vector<Slot>& program);

@@ -90,6 +90,12 @@ enum Op : uint32_t {
     //                 if no lane has d <= MIN_DIST, skip w5 slots (to OP_PORTANTA_END)
     OP_PORTANTA,      // w1-3 t, w4 r, w5 skip
     OP_PORTANTA_END,  // d = stack[slot] ; A = (d <= MIN_DIST) ? A : d
+    // Culling inside a union (min) chain.  The next w5 slots compute A = min(A, DIST(sub-tree, F))
+    // and nothing else; the sub-tree's surface lies inside the sphere (centre w1-3, F's
+    // coordinates).  If for every lane that still marches |F - c| - r exceeds A by a margin that
+    // covers every rounding error (w4 = r + margin, see scene_build.cpp), min() would return A
+    // bit for bit, and the slots are skipped.
+    OP_CULL,          // w1-3 c, w4 r + margin, w5 skip
     OP_COUNT
 };
 

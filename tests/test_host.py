@@ -132,9 +132,24 @@ def test_flatten_stock_scenes(stock_scenes):
 def test_flatten_csg1024_is_one_running_min():
     st, listing = api.flatten_scene(scenes.csg1024())
     ops = [line.split()[1] for line in listing.strip().splitlines()]
-    assert ops[0] == "MOVO" and ops[-1] == "END" and len(ops) == 343
-    assert set(ops[1:-1]) <= {"SFERO", "KUBO", "CILINDRO"}
+    assert ops[0] == "MOVO" and ops[-1] == "END"
+    # one running min over all 341 leaves, regrouped by position: a bounding-sphere test (CULL)
+    # in front of every group of more than two, no value ever pushed
+    assert set(ops[1:-1]) <= {"SFERO", "KUBO", "CILINDRO", "CULL"}
+    assert sum(op != "CULL" for op in ops[1:-1]) == 341
     assert st["value_slots"] == 0 and st["reachable"] == 1023 and st["lds_bytes"] == 1024 * 48
+    # every CULL skips a range that lies inside the program and inside its parent's range
+    rows = [line.split() for line in listing.strip().splitlines()]
+    import struct
+    ends = []
+    for pc, f in enumerate(rows):
+        while ends and pc >= ends[-1]:
+            ends.pop()
+        if f[1] == "CULL":
+            skip = struct.unpack("<I", struct.pack("<f", float(f[-3])))[0]
+            end = pc + 1 + skip
+            assert skip >= 3 and end <= len(rows) - 1 and (not ends or end <= ends[-1])
+            ends.append(end)
 
 
 def test_flatten_stack_discipline():
