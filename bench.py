@@ -6,14 +6,23 @@
 
 A step is one whole frame of the hot path: rm_set_info + one launch of the fused
 raygen/march/shadow/shade kernel over every pixel (no work is skipped or cached;
-every step re-renders the frame).  Scene table and camera block are resident on
-the device before the timed region; the framebuffer stays in HBM.
+every step re-renders the frame; the only thing a frame takes from the one
+before it is the ORDER in which its tiles are handed out, longest first).  Scene
+table and camera block are resident on the device before the timed region; the
+framebuffer stays in HBM.
+
+N = 1: one context, one stream, frames back to back (so the kernel's duration
+under rocprofv3 is the step time).  --in-flight F renders with F contexts taking
+frames in turn, each on its own stream: the tail of one frame then overlaps the
+head of the next (+13 % at 4K).
 
 N > 1: the frame is cut into row bands dealt round-robin to the ranks
 (raytracing_amd/tiling.py); each rank renders its bands, then one RCCL gather per
 frame brings them to rank 0, which interleaves them back into the frame.  The
-gather of frame k runs on a second stream under the render of frame k+1.  The
-total work is the same frame whatever N is: scaling = "strong".
+gather of frame k runs on a second stream under the render of the next frames,
+and three frames are in flight per rank (a rank's share of a frame is small and
+its time is set by the longest tile, not by the pixel count).  The total work is
+the same frame whatever N is: scaling = "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -29,6 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 flop x 2.4 GHz
+# what the vector unit issues when nothing may be contracted into an FMA (every add and multiply
+# its own instruction): tools/microbench/valu_peak.hip, v_add_f32 at 8 waves per SIMD
+FP32_VALU_NO_FMA_TFLOPS = 63.0
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -49,6 +61,19 @@ def load_nodes(scene):
 def golden_frame(scene, w, h):
     with open(os.path.join(ROOT, "tests", "golden", "frames.json")) as f:
         return json.load(f).get("%s_%dx%d" % (scene, w, h))
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the last committed counter profile of this workload (rocprofv3 --pmc
+    cannot run inside the timed region): {"bytes": ..., "source": ...} or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_v4_counters.json")) as f:
+            rec = json.load(f)
+        if rec.get("workload") == workload:
+            return {"bytes": rec["hbm_bytes_per_launch"], "source": rec["source"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(scene, w, h, info, want):
@@ -82,6 +107,7 @@ def main():
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for N>1 (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--norm-batch", type=int, default=0)
+    ap.add_argument("--in-flight", type=int, default=0, help="contexts taking frames in turn (0 = 1 for N=1, 3 for N>1)")
     args = ap.parse_args()
 
     import torch
@@ -107,52 +133,64 @@ def main():
     nodes = load_nodes(scene)
     info = O.default_info(1, 0)          # main.cpp default camera, light at +1 degree ("frame 0")
     want = golden_frame(scene, w, h)
+    in_flight = args.in_flight or (1 if world == 1 else 3)
 
-    rm = api.Raymarching(w, h, device=local_rank)
-    rm.set_nodes(nodes)
-    rm.set_info(info)
-    if args.norm_batch:
-        rm.set_norm_batch(args.norm_batch)
-    render_stream = torch.cuda.Stream(device=dev)
-    rm.set_stream(render_stream.cuda_stream)
+    # one context per frame in flight, each on a stream of its own
+    ctxs, streams = [], []
+    for _ in range(in_flight):
+        rm = api.Raymarching(w, h, device=local_rank)
+        rm.set_nodes(nodes)
+        rm.set_info(info)
+        if args.norm_batch:
+            rm.set_norm_batch(args.norm_batch)
+        st = torch.cuda.Stream(device=dev)
+        rm.set_stream(st.cuda_stream)
+        ctxs.append(rm)
+        streams.append(st)
 
     band = 0
     if world > 1:
         band = args.band_rows or tiling.default_band_rows(h, world)
-        rm.set_bands(band, rank, world)
         rows_max = tiling.bands_per_rank(h, band, world) * band
-        bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
         comm_stream = torch.cuda.Stream(device=dev)
-        rendered = [torch.cuda.Event() for _ in range(2)]
-        gathered = [torch.cuda.Event() for _ in range(2)]
-        parts = [torch.zeros((world, rows_max, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-                 for _ in range(2)]
+        bufs, parts, rendered, gathered = [], [], [], []
+        for rm in ctxs:
+            rm.set_bands(band, rank, world)
+            bufs.append(torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev))
+            rm.set_output(bufs[-1].data_ptr(), w * 4)
+            parts.append(torch.zeros((world, rows_max, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None)
+            rendered.append(torch.cuda.Event())
+            gathered.append(torch.cuda.Event())
         frame_padded = (torch.zeros((tiling.padded_rows(h, band, world), w, 4), dtype=torch.uint8, device=dev)
                         if rank == 0 else None)
         frame = frame_padded[:h] if rank == 0 else None
+        frames = [frame]
     else:
-        frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
-        rm.set_output(frame.data_ptr(), w * 4)
+        frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in ctxs]
+        for rm, f in zip(ctxs, frames):
+            rm.set_output(f.data_ptr(), w * 4)
+        frame = frames[0]
 
     def step(k):
+        j = k % in_flight
+        rm = ctxs[j]
         rm.set_info(info)
         if world == 1:
             rm.process_async()
             return
-        b = k & 1
-        render_stream.wait_event(gathered[b])          # buffer b is free again
-        rm.set_output(bufs[b].data_ptr(), w * 4)
+        streams[j].wait_event(gathered[j])             # context j's band buffer is free again
         rm.process_async()
-        rendered[b].record(render_stream)
-        comm_stream.wait_event(rendered[b])
-        with torch.cuda.stream(comm_stream):
-            dist.gather(bufs[b], list(parts[b].unbind(0)) if rank == 0 else None, dst=0)
+        rendered[j].record(streams[j])
+        comm_stream.wait_event(rendered[j])
+        with torch.cuda.stream(comm_stream):           # same order of gathers on every rank
+            dist.gather(bufs[j], list(parts[j].unbind(0)) if rank == 0 else None, dst=0)
             if rank == 0:
-                tiling.assemble_into(frame_padded, parts[b], band)
-            gathered[b].record(comm_stream)
+                tiling.assemble_into(frame_padded, parts[j], band)
+            gathered[j].record(comm_stream)
 
     def drain():
-        render_stream.synchronize()
+        for st in streams:
+            st.synchronize()
         if world > 1:
             comm_stream.synchronize()
         torch.cuda.synchronize()
@@ -166,16 +204,18 @@ def main():
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(render_stream)
+    ev0.record(streams[args.warmup % in_flight])
     for k in range(args.steps):
         step(args.warmup + k)
-    ev1.record(render_stream)
+    ev1.record(streams[(args.warmup + args.steps - 1) % in_flight])
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)     # average launch-to-launch time on the render stream
+    # N = 1, one frame in flight: the kernel's average duration (launch to launch on its stream).
+    # With frames in flight kernels overlap; the per-frame time of the region is what counts then.
+    kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / max(1, args.steps)
 
     if world > 1:
         tmax = torch.tensor([secs], dtype=torch.float64, device=dev)
@@ -197,7 +237,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
-                       "scene_nodes": int(len(nodes)), "partition": "whole frame" if world == 1 else
+                       "scene_nodes": int(len(nodes)), "frames_in_flight": in_flight,
+                       "partition": "whole frame" if world == 1 else
                        "row bands of %d dealt round-robin over %d ranks, RCCL gather to rank 0" % (band, world)},
             "parity": {"hit_pixels": hits, "rgba_sha256": sha,
                        "golden_hit_pixels": want["hits"] if want else None,
@@ -207,20 +248,29 @@ def main():
         if want:
             flops = want["counters"]["flops"] / world      # per launch: each rank renders 1/N of the frame
             achieved = flops / (kernel_ms * 1e-3) / 1e12
+            traffic = measured_traffic(args.workload) if world == 1 else None
             out["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
+                               "traffic": traffic["bytes"] if traffic else None,
+                               "traffic_source": traffic["source"] if traffic else None,
                                "algorithmic_flops_per_ray": want["flops_per_ray"],
-                               "note": "algorithmic FLOPs counted by the CPU restatement (SURVEY.md appendix D); "
-                                       "fp32 adds and multiplies are not contracted, so the attainable ceiling is "
-                                       "half the FMA peak",
+                               "peak_no_fma": FP32_VALU_NO_FMA_TFLOPS, "frac_of_no_fma_peak": achieved / FP32_VALU_NO_FMA_TFLOPS,
+                               "note": "the path is bound by fp32 vector issue, not by HBM or MFMA (SURVEY.md 8d). "
+                                       "achieved = algorithmic FLOPs of one launch, counted by the CPU restatement "
+                                       "(SURVEY.md appendix D: add/sub/mul/div/sqrt/floor/min/max = 1), over the "
+                                       "kernel's average duration; peak = 157.3 TFLOP/s of FMAs.  Results must match "
+                                       "the reference bit for bit, so nothing is contracted into an FMA and sqrt and "
+                                       "division are correctly rounded: peak_no_fma is what the chip issues then "
+                                       "(measured: tools/microbench/valu_peak.hip)",
                                "hbm": {"achieved": w * h * 4 / world / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "bytes_per_ray": 4}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, w, h, info, want)
-            out["stats"] = rm.scene_stats()
+            out["stats"] = ctxs[0].scene_stats()
         print(json.dumps(out), flush=True)
 
-    rm.close()
+    for rm in ctxs:
+        rm.close()
     if world > 1:
         dist.destroy_process_group()
 
