@@ -222,9 +222,22 @@ bool jit_build_code(const std::string& arch, const std::string& source, std::vec
     const std::string arch_opt = "--offload-arch=" + arch;
     // same arithmetic contract as the ahead-of-time build: no contraction, IEEE sqrt and division
     // (the atomic optimizer is off for the tile queue's sake: device_render.h)
-    const char* opts[] = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-                           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None" };
-    hiprtcResult r = hiprtcCompileProgram(prog, 7, opts);
+    std::vector<const char*> opts = { arch_opt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                                      // packed fp32 (v_pk_add/mul_f32) issues at 1.7x the cost of a plain op on
+                                      // gfx950 and needs moves to pair its operands: measured 6-10 % slower
+                                      "-fno-slp-vectorize",
+                                      "-mllvm", "-amdgpu-atomic-optimizer-strategy=None" };
+    // RM_JIT_FLAGS: extra compiler options, blank-separated (experiments; they become part of the cache key)
+    std::vector<std::string> extra;
+    if (const char* env = std::getenv("RM_JIT_FLAGS")) {
+        std::string cur;
+        for (const char* p = env;; ++p) {
+            if (*p == ' ' || *p == 0) { if (!cur.empty()) extra.push_back(cur); cur.clear(); if (!*p) break; }
+            else cur.push_back(*p);
+        }
+    }
+    for (const std::string& e : extra) opts.push_back(e.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, static_cast<int>(opts.size()), opts.data());
     size_t log_size = 0;
     if (log && hiprtcGetProgramLogSize(prog, &log_size) == HIPRTC_SUCCESS && log_size > 1) {
         log->resize(log_size);
@@ -245,7 +258,8 @@ hipError_t jit_compile(int device, const std::string& scene_source, JitKernels* 
     if (e != hipSuccess) return e;
     const std::string arch = props.gcnArchName;
     const std::string source = jit_full_source(scene_source);
-    const uint64_t hash = fnv1a(arch, fnv1a(source));
+    const char* flags = std::getenv("RM_JIT_FLAGS");
+    const uint64_t hash = fnv1a(flags ? flags : "", fnv1a(arch, fnv1a(source)));
 
     std::lock_guard<std::mutex> lock(g_mutex);
     auto it = g_cache.find(CacheKey{device, hash});

@@ -24,7 +24,7 @@ prelude = bundle[bundle.index('R"RMJIT(') + 8: bundle.rindex(')RMJIT"')]
 hip = os.path.join(out, name + ".hip")
 with open(hip, "w") as f:
     f.write("#include <hip/hip_runtime.h>\n#include <stdint.h>\n" + prelude + src)
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "--offload-arch=gfx950",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "--offload-arch=gfx950",
        "--cuda-device-only", "-S", "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(out, name + ".s"), hip]
 r = subprocess.run(cmd, capture_output=True, text=True)
 print(r.stderr[-3000:])
