@@ -54,6 +54,55 @@ __global__ void __launch_bounds__(256) k(float* out, float seed, unsigned long l
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// generic: 8 independent copies of one instruction text with operands %0..%7 (vgpr), %8 (vgpr const), %9 (sgpr const)
+#define GEN(NAME, TXT) \
+__global__ void __launch_bounds__(256) NAME(float* out, float seed, unsigned long long* cyc) { \
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    const float c = seed * 0.5f; float sc = seed * 0.25f; \
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(); \
+    for (int i = 0; i < N_ITER; ++i) { \
+        REP8(asm volatile(TXT(0) TXT(1) TXT(2) TXT(3) TXT(4) TXT(5) TXT(6) TXT(7) \
+             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(sc) : "vcc");) \
+    } \
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(); \
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; \
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0; \
+}
+#define T_MUL_LIT(n)  "v_mul_f32 %" #n ", 0x3f1ce861, %" #n "\n"
+#define T_ADD_SGPR(n) "v_add_f32 %" #n ", %9, %" #n "\n"
+#define T_FMAC(n)     "v_fmac_f32 %" #n ", %8, %8\n"
+#define T_FMA_LIT(n)  "v_fma_f32 %" #n ", %" #n ", %8, 1.0\n"
+#define T_MAX(n)      "v_max_f32 %" #n ", %" #n ", %8\n"
+#define T_MED3(n)     "v_med3_f32 %" #n ", %" #n ", %8, %8\n"
+#define T_CMP32(n)    "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define T_CMP64(n)    "v_cmp_lt_f32 s[20:21], %" #n ", %8\n"
+#define T_CND32(n)    "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define T_RSQ(n)      "v_rsq_f32 %" #n ", %" #n "\n"
+#define T_FLOOR(n)    "v_floor_f32 %" #n ", %" #n "\n"
+#define T_AND(n)      "v_and_b32 %" #n ", 0x7fffffff, %" #n "\n"
+#define T_ADDABS(n)   "v_add_f32_e64 %" #n ", |%" #n "|, %9\n"
+#define T_SUBNEG(n)   "v_sub_f32 %" #n ", %8, %" #n "\n"
+#define T_MOV(n)      "v_mov_b32 %" #n ", %8\n"
+GEN(g_mul_lit, T_MUL_LIT) GEN(g_add_sgpr, T_ADD_SGPR) GEN(g_fmac, T_FMAC) GEN(g_fma_lit, T_FMA_LIT) GEN(g_max, T_MAX)
+GEN(g_med3, T_MED3) GEN(g_cmp32, T_CMP32) GEN(g_cnd32, T_CND32) GEN(g_rsq, T_RSQ) GEN(g_floor, T_FLOOR)
+GEN(g_and, T_AND) GEN(g_addabs, T_ADDABS) GEN(g_sub, T_SUBNEG) GEN(g_mov, T_MOV)
+
+typedef void (*kern_t)(float*, float, unsigned long long*);
+void run_gen(const char* name, kern_t kfn, int waves_per_simd, float* d_out, unsigned long long* d_cyc) {
+    const int blocks = 256 * waves_per_simd;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), 0, 0, d_out, 1.0f, d_cyc);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), 0, 0, d_out, 1.0f, d_cyc);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double total_instr = 64.0 * N_ITER * blocks * 4;
+    printf("%-14s waves/SIMD %d  %8.3f ms  %.1f Tinstr-lanes/s  (cost vs v_add_f32 at 63: %.2f)\n", name, waves_per_simd, ms,
+           total_instr * 64 / (ms * 1e-3) / 1e12, 63.0 / (total_instr * 64 / (ms * 1e-3) / 1e12));
+}
+
 template <int KIND>
 void run(const char* name, int waves_per_simd, float* d_out, unsigned long long* d_cyc, double flops_per_instr) {
     const int blocks = 256 * waves_per_simd;      // 256 threads = 4 waves = one per SIMD of a CU
@@ -86,6 +135,22 @@ int main() {
         run<4>("add dependent", w, d_out, d_cyc, 1);
         run<5>("v_pk_mul sgpr", w, d_out, d_cyc, 2);
         run<6>("cmp+cndmask", w, d_out, d_cyc, 0);
+    }
+    for (int w : {1, 8}) {
+        run_gen("v_mul literal", g_mul_lit, w, d_out, d_cyc);
+        run_gen("v_add sgpr", g_add_sgpr, w, d_out, d_cyc);
+        run_gen("v_fmac vop2", g_fmac, w, d_out, d_cyc);
+        run_gen("v_fma inline", g_fma_lit, w, d_out, d_cyc);
+        run_gen("v_max_f32", g_max, w, d_out, d_cyc);
+        run_gen("v_med3_f32", g_med3, w, d_out, d_cyc);
+        run_gen("v_cmp vcc", g_cmp32, w, d_out, d_cyc);
+        run_gen("v_cndmask vcc", g_cnd32, w, d_out, d_cyc);
+        run_gen("v_rsq_f32", g_rsq, w, d_out, d_cyc);
+        run_gen("v_floor_f32", g_floor, w, d_out, d_cyc);
+        run_gen("v_and literal", g_and, w, d_out, d_cyc);
+        run_gen("v_add |x| sgpr", g_addabs, w, d_out, d_cyc);
+        run_gen("v_sub_f32", g_sub, w, d_out, d_cyc);
+        run_gen("v_mov_b32", g_mov, w, d_out, d_cyc);
     }
     return 0;
 }
