@@ -123,11 +123,20 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the render path")
+    # Rehearsal on a box with one GPU (RM_BENCH_REHEARSAL=1): every rank renders on device 0 and the
+    # gather goes through gloo on host copies.  Same step logic, same band layout, same assembly; the
+    # numbers it prints mean nothing.
+    rehearsal = os.environ.get("RM_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scene, w, h = WORKLOADS[args.workload]
     nodes = load_nodes(scene)
@@ -183,7 +192,15 @@ def main():
         rendered[j].record(streams[j])
         comm_stream.wait_event(rendered[j])
         with torch.cuda.stream(comm_stream):           # same order of gathers on every rank
-            dist.gather(bufs[j], list(parts[j].unbind(0)) if rank == 0 else None, dst=0)
+            if rehearsal:
+                comm_stream.synchronize()
+                host = bufs[j].cpu()
+                got = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, got, dst=0)
+                if rank == 0:
+                    parts[j].copy_(torch.stack(got))
+            else:
+                dist.gather(bufs[j], list(parts[j].unbind(0)) if rank == 0 else None, dst=0)
             if rank == 0:
                 tiling.assemble_into(frame_padded, parts[j], band)
             gathered[j].record(comm_stream)
@@ -218,7 +235,7 @@ def main():
     kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / max(1, args.steps)
 
     if world > 1:
-        tmax = torch.tensor([secs], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([secs], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         secs = float(tmax.item())
 
@@ -234,7 +251,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": secs * 1e3 / args.steps,
             "frames_per_s": args.steps / secs,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, **({"rehearsal": True} if rehearsal else {}),
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
                        "scene_nodes": int(len(nodes)), "frames_in_flight": in_flight,
