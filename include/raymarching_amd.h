@@ -148,17 +148,22 @@ int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char
  * Source/cuda_rays.cu:59-153: there the fixed kernel source is compiled at
  * start-up; here the SCENE is compiled, each node becoming straight-line code).
  * mode 0: never, every scene runs on the generic distance program;
- * mode 1 (default): scenes of up to 64 reachable nodes are compiled with hiprtc
- *         when rm_set_primitives / rm_set_nodes is called, falling back to the
- *         generic program if compilation fails (rm_get_scene_stats().jit tells);
- * mode 2: as 1, but a scene that cannot be compiled is an error.
+ * mode 1 (default): scenes are compiled with hiprtc when rm_set_primitives /
+ *         rm_set_nodes is called: up to 64 reachable nodes as one distance and one
+ *         normal function per node; larger ones (up to 4096 program slots, 64 KiB
+ *         of tree table) as their flattened distance program, normals staying on
+ *         the tree walker.  Falls back to the generic program if the scene is
+ *         larger still or compilation fails (rm_get_scene_stats().jit tells);
+ * mode 2: as 1, but a scene that cannot be compiled is an error;
+ * mode 3: as 2, and small scenes take the large-scene form too (tests).
  * Takes effect at the next scene upload.  Environment RM_JIT=<mode> sets the
  * default; RM_JIT_CACHE=<dir> keeps code objects on disk between processes. */
 int rm_set_jit(rm_ctx* ctx, int mode);
 int rm_jit_log(rm_ctx* ctx, char* buf, size_t cap);
 /* Host-only: generate and compile the code of a scene for `arch` without a
  * device.  text receives the generated source (want_source & 1) or the log; want_source & 2 generates
- * as if every divisor constant had been proved on a device (inspection only). */
+ * as if every divisor constant had been proved on a device, want_source & 4 in the
+ * large-scene form whatever the size (inspection only). */
 int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_source, char* text, size_t cap);
 
 /* Tuning: how many of a wavefront's lanes must be waiting for a surface normal

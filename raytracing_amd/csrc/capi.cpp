@@ -196,6 +196,22 @@ hipError_t exact_divisors(rm_ctx* c, const rm_node* nodes, size_t n, rm::Divisor
     return hipSuccess;
 }
 
+// Generated source for a flattened scene and the dynamic LDS its kernels need; false if the
+// scene is too large for code generation (jit.h).
+bool jit_source(const rm_node* nodes, size_t n, const rm::SceneBuild& built, const rm::DivisorSet* exact,
+                bool force_program, std::string* src, size_t* lds_bytes) {
+    if (built.reachable <= rm::kJitMaxNodes && !force_program) {
+        *src = rm::generate_scene_source(nodes, n, built.seen.data(), exact);
+        *lds_bytes = 0;
+        return true;
+    }
+    const size_t tree_bytes = built.tree.size() * sizeof(rm::TreeNode);
+    if (built.program.size() > rm::kJitMaxSlots || tree_bytes > rm::kJitMaxLds) return false;
+    *src = rm::generate_program_source(built.program, built.value_slots, built.slot_node, built.union_rank);
+    *lds_bytes = built.union_rank.empty() ? tree_bytes : 0;
+    return true;
+}
+
 int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     HIP_TRY(hipSetDevice(c->device));
     rm::DivisorSet exact;
@@ -225,12 +241,13 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     bool jit_ok = false;
     rm::JitKernels jit;
     c->jit_log.clear();
-    if (c->jit_mode != 0 && built.reachable <= rm::kJitMaxNodes) {
-        const std::string src = rm::generate_scene_source(nodes, n, built.seen.data(), &exact);
-        hipError_t je = rm::jit_compile(c->device, src, &jit, &c->jit_log);
+    std::string src;
+    size_t jit_lds = 0;
+    if (c->jit_mode != 0 && jit_source(nodes, n, built, &exact, c->jit_mode == 3, &src, &jit_lds)) {
+        hipError_t je = rm::jit_compile(c->device, src, jit_lds, &jit, &c->jit_log);
         jit_ok = je == hipSuccess;
-        if (!jit_ok && c->jit_mode == 2) { (void)hipFree(d_prog); (void)hipFree(d_tree); return RM_ERR_JIT; }
-    } else if (c->jit_mode == 2) {
+        if (!jit_ok && c->jit_mode >= 2) { (void)hipFree(d_prog); (void)hipFree(d_tree); return RM_ERR_JIT; }
+    } else if (c->jit_mode >= 2) {
         (void)hipFree(d_prog); (void)hipFree(d_tree);
         return RM_ERR_TOO_LARGE;
     }
@@ -277,7 +294,7 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     rm_ctx* c = new (std::nothrow) rm_ctx;
     if (!c) return static_cast<int>(hipErrorOutOfMemory);
     c->device = device; c->width = width; c->height = height;
-    if (const char* env = std::getenv("RM_JIT")) c->jit_mode = std::atoi(env) < 0 ? 0 : std::atoi(env) > 2 ? 2 : std::atoi(env);
+    if (const char* env = std::getenv("RM_JIT")) c->jit_mode = std::atoi(env) < 0 ? 0 : std::atoi(env) > 3 ? 3 : std::atoi(env);
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -511,7 +528,7 @@ int rm_debug_wave_stats(rm_ctx* c, uint32_t* host_out, size_t cap_waves, size_t*
 }
 
 int rm_set_jit(rm_ctx* c, int mode) {
-    if (!c || mode < 0 || mode > 2) return RM_ERR_INVALID_ARG;
+    if (!c || mode < 0 || mode > 3) return RM_ERR_INVALID_ARG;
     c->jit_mode = mode;
     return RM_OK;
 }
@@ -528,15 +545,19 @@ int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_sour
     rm::SceneBuild built;
     int rc = rm::build_scene(nodes, n, built);
     if (rc != RM_OK) return rc;
-    if (built.reachable > rm::kJitMaxNodes) return RM_ERR_TOO_LARGE;
     // want_source & 2: generate as if the device had proved every divisor in range (ISA inspection only)
     rm::DivisorSet assumed;
-    if (want_source & 2)
+    if (want_source & 2) {
         for (float v : rm::scene_divisors(nodes, n)) {
             const float m = v < 0 ? -v : v;
             if (m >= 0x1p-20f && m <= 0x1p20f) { uint32_t u; std::memcpy(&u, &v, 4); assumed.insert(u); }
         }
-    const std::string scene = rm::generate_scene_source(nodes, n, built.seen.data(), &assumed);
+        rc = rm::build_scene(nodes, n, built, &assumed);
+        if (rc != RM_OK) return rc;
+    }
+    std::string scene;
+    size_t lds = 0;
+    if (!jit_source(nodes, n, built, &assumed, (want_source & 4) != 0, &scene, &lds)) return RM_ERR_TOO_LARGE;
     std::string log;
     std::vector<char> code;
     const bool ok = rm::jit_build_code(arch ? arch : "gfx950", rm::jit_full_source(scene), &code, &log);

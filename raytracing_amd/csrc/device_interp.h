@@ -101,13 +101,9 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
         if (__builtin_amdgcn_ballot_w64(d <= RM_MIN_DIST) == 0) skip = w[5];
         break;
     }
-    case OP_CULL: {                // scene_program.h; lanes that do not march have no say
-        const float dx = S.x - f1, dy = S.y - f2, dz = S.z - f3;
-        const float s2 = dx * dx + dy * dy + dz * dz, T = m.A + f4;
-        const bool far = T < 0.f || s2 > T * T * 1.001953125f;      // false for NaN: never culls
-        if (__builtin_amdgcn_ballot_w64(active && !far) == 0) skip = w[5];
+    case OP_CULL:                  // scene_program.h; lanes that do not march have no say
+        if (cull_all(S, m.A, active, f1, f2, f3, f4)) skip = w[5];
         break;
-    }
     case OP_PORTANTA_END: {
         float d = stack[slot * RM_BLOCK_THREADS];
         m.A = (d <= RM_MIN_DIST) ? m.A : d;

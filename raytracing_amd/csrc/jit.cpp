@@ -44,6 +44,33 @@ void build_q(const rm_node& nd, float Q[9]) {
     Q[0] = xx; Q[1] = xy; Q[2] = xz; Q[3] = yx; Q[4] = yy; Q[5] = yz; Q[6] = zx; Q[7] = zy; Q[8] = zz;
 }
 
+// the two kernels built on a JitScene, whichever generator wrote it
+const char kJitKernels[] = R"(
+extern "C" __global__ void __launch_bounds__(RM_BLOCK_THREADS) rm_render_jit(const rm::RenderParams prm) {
+    rm::render_body<rm::JitScene>(prm);
+}
+
+extern "C" __global__ void __launch_bounds__(RM_BLOCK_THREADS)
+rm_eval_points_jit(const rm::RenderParams prm, const float* __restrict__ xyz, uint32_t count,
+                   float* __restrict__ dist_out, float* __restrict__ norm_out) {
+    rm::JitScene scene;
+    rm::JitScene::Scratch scratch;
+    scene.init(prm);
+    const uint32_t i = blockIdx.x * RM_BLOCK_THREADS + threadIdx.x;
+    const bool live = i < count;
+    rm::P3 p{0.f, 0.f, 0.f};
+    if (live) p = rm::P3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    const float d = scene.dist(p, scratch, live);          // wave-uniform code: every lane runs it
+    if (live) {
+        dist_out[i] = d;
+        if (norm_out) {
+            rm::P3 N = scene.norm(p, scratch);
+            norm_out[3 * i] = N.x; norm_out[3 * i + 1] = N.y; norm_out[3 * i + 2] = N.z;
+        }
+    }
+}
+)";
+
 uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
     for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
     return h;
@@ -155,23 +182,184 @@ struct JitScene {
 };
 }  // namespace rm
 
-extern "C" __global__ void __launch_bounds__(RM_BLOCK_THREADS) rm_render_jit(const rm::RenderParams prm) {
-    rm::render_body<rm::JitScene>(prm);
+)";
+    s += kJitKernels;
+    return s;
 }
 
-extern "C" __global__ void __launch_bounds__(RM_BLOCK_THREADS)
-rm_eval_points_jit(const rm::RenderParams prm, const float* __restrict__ xyz, uint32_t count,
-                   float* __restrict__ dist_out, float* __restrict__ norm_out) {
-    const uint32_t i = blockIdx.x * RM_BLOCK_THREADS + threadIdx.x;
-    if (i >= count) return;
-    rm::P3 p{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-    dist_out[i] = rm::d0(p);
-    if (norm_out) {
-        rm::P3 N = rm::n0(p);
-        norm_out[3 * i] = N.x; norm_out[3 * i + 1] = N.y; norm_out[3 * i + 2] = N.z;
+// =============================================================================
+// Large scenes: the distance PROGRAM (scene_program.h) turned into straight-line
+// code, slot by slot, with the same helpers and the same combine (v_med3_f32) as
+// the interpreter, so it returns the interpreter's bits.  Skip ranges
+// (OP_PORTANTA, OP_CULL) become wave-uniform branches; LDS value slots become
+// locals.  Normals stay on the tree walker over the LDS tree table: a normal
+// function per node would inline every sub-tree's distance code at every level.
+// =============================================================================
+namespace {
+
+std::string slot_f(const Slot& sl, int k) { float v; std::memcpy(&v, &sl.w[k], 4); return lit(v); }
+
+// ranks != nullptr: selection mode (generate_program_source, scene_norm): a primitive slot also
+// records itself in `best` if it lowers A, or equals it and outranks the holder
+void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string& s, int indent,
+                const std::vector<int32_t>* slot_node = nullptr, const std::vector<uint32_t>* ranks = nullptr) {
+    const std::string pad(static_cast<size_t>(indent) * 4, ' ');
+    for (size_t pc = lo; pc < hi; ++pc) {
+        const Slot& sl = prog[pc];
+        const uint32_t w0 = sl.w[0], op = w0 & 0xff, slot = w0 >> F_SLOT_SHIFT;
+        const std::string S = (w0 & F_SRC_F) ? "F" : "P";
+        const std::string sel = (w0 & (COMB_MAX << F_COMB_SHIFT)) ? "as_f(0x7f800000u)" : "as_f(0xff800000u)";
+        const std::string neg = (w0 & F_NEG) ? "-" : "";
+        const std::string f1 = slot_f(sl, 1), f2 = slot_f(sl, 2), f3 = slot_f(sl, 3), f4 = slot_f(sl, 4),
+                          f5 = slot_f(sl, 5), f6 = slot_f(sl, 6);
+        const std::string V = "s" + std::to_string(slot);
+        const std::string to_f = (w0 & F_DST_F) ? " F = P;" : "";
+        auto prim = [&](const std::string& call) {
+            if (!ranks) { s += pad + "A = __builtin_amdgcn_fmed3f(A, " + neg + call + ", " + sel + ");\n"; return; }
+            const std::string rk = std::to_string((*ranks)[static_cast<size_t>((*slot_node)[pc])]) + "u";
+            s += pad + "{ const float v = " + neg + call + "; const bool take = v < A || (v == A && " + rk + " > brank); " +
+                 "A = take ? v : A; best = take ? " + std::to_string(pc) + "u : best; brank = take ? " + rk + " : brank; }\n";
+        };
+        const std::string moved = "movo(" + S + ", " + f1 + ", " + f2 + ", " + f3 + ")";
+        switch (op) {
+        case OP_END: return;
+        case OP_MOVO:    s += pad + "P = " + moved + ";" + to_f + "\n"; break;
+        case OP_ROTX:    s += pad + "P = rotx(" + S + ", " + f1 + ", " + f2 + ");" + to_f + "\n"; break;
+        case OP_ROTY:    s += pad + "P = roty(" + S + ", " + f1 + ", " + f2 + ");" + to_f + "\n"; break;
+        case OP_ROTZ:    s += pad + "P = rotz(" + S + ", " + f1 + ", " + f2 + ");" + to_f + "\n"; break;
+        case OP_ROTQ_XY:
+            s += pad + "tx = " + S + ".x + 2.f * (" + f1 + " * " + S + ".x + " + f2 + " * " + S + ".y + " + f3 + " * " + S + ".z);\n";
+            s += pad + "ty = " + S + ".y + 2.f * (" + f4 + " * " + S + ".x + " + f5 + " * " + S + ".y + " + f6 + " * " + S + ".z);\n";
+            break;
+        case OP_ROTQ_Z:
+            s += pad + "P = P3{tx, ty, " + S + ".z + 2.f * (" + f1 + " * " + S + ".x + " + f2 + " * " + S + ".y + " + f3 + " * " + S + ".z)};" + to_f + "\n";
+            break;
+        case OP_RIPETO:  s += pad + "P = ripeto(" + S + ", " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ", " + f5 + ");" + to_f + "\n"; break;
+        case OP_SETF:    s += pad + "F = P;\n"; break;
+        case OP_SFERO:   prim("sfero_dist(" + moved + ", " + f4 + ")"); break;
+        case OP_KUBO:    prim("kubo_dist(" + moved + ", " + f4 + ", " + f5 + ", " + f6 + ")"); break;
+        case OP_CILINDRO:prim("cilindro_dist(" + moved + ", " + f4 + ", " + f5 + ")"); break;
+        case OP_EBENO:   prim("ebeno_dist(" + moved + ", " + f4 + ", " + f5 + ", " + f6 + ")"); break;
+        case OP_PUSHA_R: s += pad + "B = A; A = __builtin_inff();\n"; break;
+        case OP_POPC_R:  s += pad + "A = __builtin_amdgcn_fmed3f(B, A, " + sel + ");\n"; break;
+        case OP_PUSHA:   s += pad + V + " = A; A = __builtin_inff();\n"; break;
+        case OP_POPC:    s += pad + "A = __builtin_amdgcn_fmed3f(" + V + ", A, " + sel + ");\n"; break;
+        case OP_NEG:     s += pad + "A = -A;\n"; break;
+        case OP_GLATA_R: s += pad + "A = glata(B, A, " + f1 + ", " + f2 + ", " + ((w0 & F_NEG) ? "true" : "false") + ");\n"; break;
+        case OP_GLATA:   s += pad + "A = glata(" + V + ", A, " + f1 + ", " + f2 + ", " + ((w0 & F_NEG) ? "true" : "false") + ");\n"; break;
+        case OP_PUSHF:
+            s += pad + V + " = F.x; s" + std::to_string(slot + 1) + " = F.y; s" + std::to_string(slot + 2) + " = F.z; F = P;\n";
+            break;
+        case OP_POPF:
+            s += pad + "F = P3{" + V + ", s" + std::to_string(slot + 1) + ", s" + std::to_string(slot + 2) + "};\n";
+            break;
+        case OP_PORTANTA: {            // Source/cuda_kernels.cu:53-61
+            const size_t skip = sl.w[5];
+            s += pad + "P = " + moved + "; " + V + " = length_3(P.x, P.y, P.z) - " + f4 + ";\n";
+            s += pad + "if (__builtin_amdgcn_ballot_w64(" + V + " <= RM_MIN_DIST) != 0) {\n";
+            emit_range(prog, pc + 1, pc + 1 + skip, s, indent + 1, slot_node, ranks);
+            s += pad + "}\n";
+            pc += skip;
+            break;
+        }
+        case OP_PORTANTA_END: s += pad + "A = (" + V + " <= RM_MIN_DIST) ? A : " + V + ";\n"; break;
+        case OP_CULL: {                // scene_program.h
+            const size_t skip = sl.w[5];
+            s += pad + "if (!cull_all(" + S + ", A, active, " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ")) {\n";
+            emit_range(prog, pc + 1, pc + 1 + skip, s, indent + 1, slot_node, ranks);
+            s += pad + "}\n";
+            pc += skip;
+            break;
+        }
+        default: break;
+        }
     }
 }
+
+}  // namespace
+
+std::string generate_program_source(const std::vector<Slot>& program, uint32_t value_slots,
+                                    const std::vector<int32_t>& slot_node, const std::vector<uint32_t>& union_rank) {
+    std::string s = "namespace rm {\n";
+    s += "__device__ __forceinline__ float scene_program(P3 E, bool active) {\n";
+    s += "    P3 F = E, P = E; float A = __builtin_inff(), B = 0.f, tx = 0.f, ty = 0.f;\n";
+    if (value_slots) {
+        s += "    float";
+        for (uint32_t k = 0; k < value_slots; ++k) s += std::string(k ? "," : "") + " s" + std::to_string(k) + " = 0.f";
+        s += ";\n";
+    }
+    emit_range(program, 0, program.size(), s, 1);
+    s += "    (void)B; (void)tx; (void)ty; (void)F; (void)P;\n    return A;\n}\n";
+
+    if (union_rank.empty()) {
+        // normals by the tree walker over the LDS tree table: a normal function per node would
+        // inline every sub-tree's distance code at every level
+        s += R"(
+struct JitScene {
+    const TreeNode* tree;
+    typedef WalkStack Scratch;
+    __device__ __forceinline__ void init(const RenderParams& prm) {
+        extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+        tree = reinterpret_cast<const TreeNode*>(lds);
+        stage_tree(prm.tree, prm.n_nodes, lds);
+    }
+    __device__ __forceinline__ float dist(P3 p, Scratch&, bool active) { return scene_program(p, active); }
+    __device__ __forceinline__ P3 norm(P3 p, Scratch& st) { return walk_norm(tree, 0, p, st); }
+};
+}  // namespace rm
 )";
+        s += kJitKernels;
+        return s;
+    }
+
+    // The scene is transforms over one union of primitives (SceneBuild::union_rank): its normal is
+    // the normal of the member with the smallest distance, equal distances resolved as the
+    // reference's nested kunigajo_N do.  One pass over the members, culled like the distance
+    // program (a culled group is farther than A by a margin: it holds neither the minimum nor a
+    // tie), then the winner's own normal, carried back through the rotations above the union.
+    s += "__device__ __forceinline__ P3 scene_norm(P3 E) {\n";
+    s += "    const bool active = true;     // called by the lanes that need a normal: the others are masked off\n";
+    s += "    P3 F = E, P = E; float A = __builtin_inff(), tx = 0.f, ty = 0.f; uint32_t best = 0u, brank = 0u;\n";
+    emit_range(program, 0, program.size(), s, 1, &slot_node, &union_rank);
+    s += "    (void)tx; (void)ty; (void)P; (void)brank;\n    P3 N{0.f, 0.f, 0.f};\n    switch (best) {\n";
+    std::vector<std::string> back;            // rotations met on the way down, to undo on the way up
+    for (size_t pc = 0; pc < program.size(); ++pc) {
+        const Slot& sl = program[pc];
+        const uint32_t w0 = sl.w[0], op = w0 & 0xff;
+        if (op == OP_END) break;
+        const std::string f1 = slot_f(sl, 1), f2 = slot_f(sl, 2), f3 = slot_f(sl, 3), f4 = slot_f(sl, 4),
+                          f5 = slot_f(sl, 5), f6 = slot_f(sl, 6);
+        if (op == OP_ROTX) back.push_back("N = rotx_back(N, " + f1 + ", " + f2 + ");");
+        if (op == OP_ROTY) back.push_back("N = roty_back(N, " + f1 + ", " + f2 + ");");
+        if (op == OP_ROTZ) back.push_back("N = rotz_back(N, " + f1 + ", " + f2 + ");");
+        if (op == OP_ROTQ_XY) {
+            const Slot& z = program[pc + 1];      // always followed by its OP_ROTQ_Z
+            back.push_back("N = rotq_back(N, " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ", " + f5 + ", " + f6 + ", " +
+                           slot_f(z, 1) + ", " + slot_f(z, 2) + ", " + slot_f(z, 3) + ");");
+        }
+        if (op < OP_SFERO || op > OP_EBENO) continue;
+        const std::string q = "movo(F, " + f1 + ", " + f2 + ", " + f3 + ")";
+        std::string nrm;
+        if (op == OP_SFERO) nrm = q;
+        else if (op == OP_KUBO) nrm = "kubo_norm(" + q + ", " + f4 + ", " + f5 + ", " + f6 + ")";
+        else if (op == OP_CILINDRO) nrm = "cilindro_norm(" + q + ", " + f4 + ", " + f5 + ")";
+        else nrm = "P3{" + f4 + ", " + f5 + ", " + f6 + "}";
+        if (w0 & F_NEG) nrm = "neg3(" + nrm + ")";
+        s += "    case " + std::to_string(pc) + "u: N = " + nrm + "; break;\n";
+    }
+    s += "    default: break;\n    }\n";
+    for (size_t k = back.size(); k-- > 0;) s += "    " + back[k] + "\n";
+    s += "    return N;\n}\n";
+    s += R"(
+struct JitScene {
+    struct Scratch {};
+    __device__ __forceinline__ void init(const RenderParams&) {}
+    __device__ __forceinline__ float dist(P3 p, Scratch&, bool active) { return scene_program(p, active); }
+    __device__ __forceinline__ P3 norm(P3 p, Scratch&) { return scene_norm(p); }
+};
+}  // namespace rm
+)";
+    s += kJitKernels;
     return s;
 }
 
@@ -184,7 +372,8 @@ struct CacheKey {
 std::mutex g_mutex;
 std::map<CacheKey, JitKernels> g_cache;      // modules live until the process ends
 
-hipError_t load_module(const std::vector<char>& code, JitKernels* out) {
+hipError_t load_module(const std::vector<char>& code, size_t lds_bytes, JitKernels* out) {
+    out->lds_bytes = lds_bytes;
     hipError_t e = hipModuleLoadData(&out->module, code.data());
     if (e != hipSuccess) return e;
     e = hipModuleGetFunction(&out->render, out->module, "rm_render_jit");
@@ -193,7 +382,7 @@ hipError_t load_module(const std::vector<char>& code, JitKernels* out) {
         (void)hipFuncGetAttribute(&out->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, out->render);
         (void)hipFuncGetAttribute(&out->scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, out->render);
         int occ = 0;
-        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, out->render, RM_BLOCK_THREADS, 0) == hipSuccess && occ > 0)
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&occ, out->render, RM_BLOCK_THREADS, lds_bytes) == hipSuccess && occ > 0)
             out->blocks_per_cu = occ;
     }
     return e;
@@ -252,7 +441,7 @@ bool jit_build_code(const std::string& arch, const std::string& source, std::vec
     return !code->empty();
 }
 
-hipError_t jit_compile(int device, const std::string& scene_source, JitKernels* out, std::string* log) {
+hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_bytes, JitKernels* out, std::string* log) {
     hipDeviceProp_t props;
     hipError_t e = hipGetDeviceProperties(&props, device);
     if (e != hipSuccess) return e;
@@ -286,7 +475,7 @@ hipError_t jit_compile(int device, const std::string& scene_source, JitKernels* 
     }
     JitKernels k;
     e = hipSetDevice(device);
-    if (e == hipSuccess) e = load_module(code, &k);
+    if (e == hipSuccess) e = load_module(code, lds_bytes, &k);
     if (e != hipSuccess) { if (k.module) (void)hipModuleUnload(k.module); return e; }
     g_cache[CacheKey{device, hash}] = k;
     *out = k;
@@ -296,7 +485,7 @@ hipError_t jit_compile(int device, const std::string& scene_source, JitKernels* 
 hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, unsigned blocks, hipStream_t stream) {
     RenderParams copy = prm;
     void* args[] = { &copy };
-    return hipModuleLaunchKernel(k.render, blocks, 1, 1, RM_BLOCK_THREADS, 1, 1, 0, stream, args, nullptr);
+    return hipModuleLaunchKernel(k.render, blocks, 1, 1, RM_BLOCK_THREADS, 1, 1, static_cast<unsigned>(k.lds_bytes), stream, args, nullptr);
 }
 
 hipError_t jit_launch_eval_points(const JitKernels& k, const RenderParams& prm, const float* xyz, uint32_t count,
@@ -304,7 +493,7 @@ hipError_t jit_launch_eval_points(const JitKernels& k, const RenderParams& prm, 
     RenderParams copy = prm;
     void* args[] = { &copy, &xyz, &count, &dist_out, &norm_out };
     const unsigned blocks = (count + RM_BLOCK_THREADS - 1) / RM_BLOCK_THREADS;
-    return hipModuleLaunchKernel(k.eval_points, blocks, 1, 1, RM_BLOCK_THREADS, 1, 1, 0, stream, args, nullptr);
+    return hipModuleLaunchKernel(k.eval_points, blocks, 1, 1, RM_BLOCK_THREADS, 1, 1, static_cast<unsigned>(k.lds_bytes), stream, args, nullptr);
 }
 
 }  // namespace rm

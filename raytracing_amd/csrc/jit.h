@@ -20,8 +20,13 @@
 
 namespace rm {
 
-// largest scene (reachable nodes) that is turned into code; bigger ones run on the interpreter
+// Scenes of up to kJitMaxNodes reachable nodes get a distance and a normal function per node
+// (generate_scene_source).  Larger ones, up to kJitMaxSlots program slots and 64 KiB of tree
+// table, get their distance program compiled (generate_program_source) and keep the tree walker
+// for normals; beyond that the interpreter runs.
 constexpr uint32_t kJitMaxNodes = 64;
+constexpr uint32_t kJitMaxSlots = 4096;
+constexpr size_t   kJitMaxLds   = 64 * 1024;
 
 struct JitKernels {
     hipModule_t   module = nullptr;
@@ -29,11 +34,18 @@ struct JitKernels {
     hipFunction_t eval_points = nullptr;
     int vgprs = 0, scratch = 0;
     int blocks_per_cu = 1;      // resident workgroups per CU of `render`
+    size_t lds_bytes = 0;       // dynamic LDS both kernels are launched with (the tree table, for large scenes)
 };
 
 // HIP source of the d<i>/n<i> function pairs of every reachable node plus the
 // kernels built on them.  `seen[i]` marks reachable nodes (scene_build).
 std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen, const DivisorSet* exact = nullptr);
+
+// The same kernels from the flattened distance program of a large scene.
+// slot_node / union_rank: SceneBuild's; with a non-empty union_rank normals come from one pass over
+// the union's members and the kernels need no LDS, else from the tree walker.
+std::string generate_program_source(const std::vector<Slot>& program, uint32_t value_slots,
+                                    const std::vector<int32_t>& slot_node, const std::vector<uint32_t>& union_rank);
 
 // prelude (flattened device headers) + scene source: what hiprtc is given
 std::string jit_full_source(const std::string& scene_source);
@@ -42,7 +54,7 @@ bool jit_build_code(const std::string& arch, const std::string& source, std::vec
 
 // Compile (or fetch from the cache) the kernels of `scene_source` for `device`.
 // Returns hipSuccess, or an error with the compiler log in *log.
-hipError_t jit_compile(int device, const std::string& scene_source, JitKernels* out, std::string* log);
+hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_bytes, JitKernels* out, std::string* log);
 
 hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, unsigned blocks, hipStream_t stream);
 hipError_t jit_launch_eval_points(const JitKernels& k, const RenderParams& prm, const float* xyz, uint32_t count,

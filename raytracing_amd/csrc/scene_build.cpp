@@ -126,6 +126,7 @@ struct Flattener {
     const DivisorSet* exact = nullptr;
     bool cull = true;                // emit OP_CULL in union chains
     std::vector<Slot> prog;
+    std::vector<int32_t> slot_node;  // parallel to prog
     std::vector<unsigned char> seen;
     uint32_t sp = 0, max_sp = 0;     // LDS stack depth in dwords
     bool f_live = false;             // an enclosing combinator still needs F
@@ -138,6 +139,7 @@ struct Flattener {
         Slot s; std::memset(&s, 0, sizeof s);
         s.w[0] = op | flags;
         prog.push_back(s);
+        slot_node.push_back(-1);
         last_xf = -1;
         if (prog.size() > kMaxProgramSlots) err = RM_ERR_TOO_LARGE;
         return prog.back();
@@ -172,6 +174,7 @@ struct Flattener {
         // a komplemento BELOW the movo negates the same value, so one flag covers
         // every order in which the two kinds of wrapper were nested
         Slot& s = emit(op, (src == SRC_F ? F_SRC_F : 0) | (neg ? F_NEG : 0) | (comb << F_COMB_SHIFT));
+        slot_node.back() = static_cast<int32_t>(idx);
         s.w[1] = fbits(t[0]); s.w[2] = fbits(t[1]); s.w[3] = fbits(t[2]);
         for (int k = 0; k < node_floats(nd.type); ++k) s.w[4 + k] = fbits(nd.f[k]);
         if (depth + hops + 1 > max_depth) max_depth = depth + hops + 1;
@@ -457,6 +460,59 @@ struct Flattener {
         if (at >= 0) prog[static_cast<size_t>(at)].w[5] = static_cast<uint32_t>(prog.size() - (static_cast<size_t>(at) + 1));
     }
 
+    // ---- normals of a scene that is one union of primitives ------------------------------
+    // NORM(kunigajo_2) forwards to child 0 if d0 < d1, else to child 1 (Source/cuda_kernels.cu:153);
+    // kunigajo_3/4 forward to the first child with the smallest distance (:179,186,217,224,231).
+    // d_k is the exact minimum over the child's members, so the nested choice picks, among the
+    // members with the smallest distance, the first one in this order: at a binary union the
+    // members of child 1 before those of child 0, at a 3- or 4-way union child 0 first.
+    void priority_order(size_t idx, std::vector<size_t>& out, uint32_t guard = 0) {
+        if (idx >= n || guard > kMaxTreeDepth) return;
+        const rm_node& nd = nodes[idx];
+        if (!is_union(nd.type)) { out.push_back(idx); return; }
+        const int na = node_arity(nd.type);
+        auto kid = [&](int k) -> size_t { int32_t o = nd.o[k]; return o > 0 ? idx + static_cast<size_t>(o) : n; };
+        if (na == 2) { priority_order(kid(1), out, guard + 1); priority_order(kid(0), out, guard + 1); }
+        else for (int k = 0; k < na; ++k) priority_order(kid(k), out, guard + 1);
+    }
+    // union_rank of SceneBuild: non-empty iff the program is [transforms]* then only primitive
+    // slots (min, source F) and culls, and those primitives are exactly the members of the union
+    // found below the root's transforms.
+    std::vector<uint32_t> single_union_ranks(const std::vector<Slot>& program, const std::vector<int32_t>& slot_nodes) {
+        std::vector<uint32_t> none;
+        size_t pc = 0;
+        auto opof = [&](size_t at) { return program[at].w[0] & 0xff; };
+        while (pc < program.size() && (opof(pc) == OP_MOVO || opof(pc) == OP_ROTX || opof(pc) == OP_ROTY || opof(pc) == OP_ROTZ ||
+                                       opof(pc) == OP_ROTQ_XY || opof(pc) == OP_ROTQ_Z || opof(pc) == OP_RIPETO || opof(pc) == OP_SETF)) ++pc;
+        size_t prims = 0;
+        for (; pc < program.size() && opof(pc) != OP_END; ++pc) {
+            const uint32_t w0 = program[pc].w[0], op = w0 & 0xff;
+            if (op == OP_CULL) continue;
+            if (op < OP_SFERO || op > OP_EBENO) return none;
+            if (!(w0 & F_SRC_F) || ((w0 & F_COMB_MASK) >> F_COMB_SHIFT) != COMB_MIN || slot_nodes[pc] < 0) return none;
+            ++prims;
+        }
+        if (prims < 2) return none;
+        size_t at = 0;                               // the union below the root's transforms
+        for (uint32_t hops = 0; at < n && hops <= kMaxTreeDepth; ++hops) {
+            const uint32_t ty = nodes[at].type;
+            if (is_union(ty)) break;
+            if (ty != RM_TYPE_MOVO && ty != RM_TYPE_ROTACIOX && ty != RM_TYPE_ROTACIOY && ty != RM_TYPE_ROTACIOZ &&
+                ty != RM_TYPE_ROTACIOQ && ty != RM_TYPE_SENFINA_RIPETO) return none;
+            if (nodes[at].o[0] <= 0) return none;
+            at += static_cast<size_t>(nodes[at].o[0]);
+        }
+        if (at >= n || !is_union(nodes[at].type)) return none;
+        std::vector<size_t> order;
+        priority_order(at, order);
+        if (order.size() != prims) return none;
+        std::vector<uint32_t> rank(n, 0);
+        for (size_t k = 0; k < order.size(); ++k) rank[order[k]] = static_cast<uint32_t>(order.size() - k);
+        for (size_t k = 0; k < program.size(); ++k)
+            if (slot_nodes[k] >= 0 && rank[static_cast<size_t>(slot_nodes[k])] == 0) return none;   // a member the order does not know
+        return rank;
+    }
+
     // ---- unions as bounding-volume hierarchies -------------------------------------------
     // min is exact, commutative and associative, so the members of a union chain may be
     // evaluated in any order and grouping (only the sign of a zero can differ).
@@ -641,6 +697,8 @@ int build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSe
     fl.emit(OP_END);      // the interpreter fetches one slot past the one it executes
     if (fl.err) return fl.err;
     out.program.swap(fl.prog);
+    out.slot_node.swap(fl.slot_node);
+    out.union_rank = fl.single_union_ranks(out.program, out.slot_node);
     out.value_slots = fl.max_sp;
     out.tree_depth = fl.max_depth;
     out.reachable = 0;

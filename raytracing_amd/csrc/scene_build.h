@@ -24,6 +24,15 @@ struct SceneBuild {
     uint32_t tree_depth  = 0;
     uint32_t reachable   = 0;
     std::vector<unsigned char> seen; // 1 for nodes reachable from node 0
+    // For every slot that evaluates a primitive: the node at which its fused chain
+    // (komplemento* / movo / primitive) starts, else -1.
+    std::vector<int32_t> slot_node;
+    // If the whole scene is transforms over ONE union chain of such primitives (the usual
+    // shape of a large scene): for each of those start nodes its rank in the order in which
+    // the reference's nested kunigajo_N normals resolve equal distances (higher wins), so that
+    // a single pass over the members finds the member whose normal the reference returns.
+    // Empty otherwise.
+    std::vector<uint32_t> union_rank;   // indexed by node
 };
 
 int  node_arity(uint32_t type);      // child links, -1 for nenio/unknown

@@ -43,7 +43,7 @@ def same_floats(a, b):
 
 # the three device evaluators of DIST(root, p): per-scene generated code (hiprtc),
 # the wave-uniform distance program, the per-lane tree walker -> (jit mode, evaluator)
-PATHS = {"jit": (2, 0), "program": (0, 0), "walker": (0, 1)}
+PATHS = {"jit": (2, 0), "jitprog": (3, 0), "program": (0, 0), "walker": (0, 1)}
 
 
 def gpu_render(nodes, w, h, info, path="jit", norm_batch=None):
@@ -74,6 +74,11 @@ def test_node_kat(name):
         d_prog, _ = rm.eval_points(pts, 0, which=0, want_norm=False)
         d_walk, n_walk = rm.eval_points(pts, 0, which=1, want_norm=True)
         d_jit, n_jit = rm.eval_points(pts, 0, which=2, want_norm=True)
+        rm.set_jit(3)                              # the distance program compiled, normals by the walker
+        rm.set_nodes(table)
+        d_jp, n_jp = rm.eval_points(pts, 0, which=2, want_norm=True)
+    assert same_floats(d_jp, want_d), "compiled distance program DIST differs from the oracle"
+    assert same_floats(n_jp, want_n), "compiled distance program NORM differs from the oracle"
     assert same_floats(d_walk, want_d), "tree walker DIST differs from the oracle"
     assert same_floats(d_prog, want_d), "distance program DIST differs from the oracle"
     assert same_floats(n_walk, want_n), "tree walker NORM differs from the oracle"
@@ -150,17 +155,18 @@ def test_csg1024_frame():
     table = scenes.csg1024()
     info = O.default_info(1, 0)
     w, h = 256, 144
-    rgba, hit, _ = gpu_render(table, w, h, info, "program")     # too large for generated code
+    rgba, hit, _ = gpu_render(table, w, h, info, "program")
     ref = O.render(table, w, h, info, threads=min(16, os.cpu_count() or 4))
     assert ref["hit"].sum() > 0
     assert np.array_equal(hit, ref["hit"])
     assert np.array_equal(rgba, ref["rgba"])
-    rgba_w, hit_w, _ = gpu_render(table, w, h, info, "walker")
-    assert np.array_equal(rgba_w, rgba) and np.array_equal(hit_w, hit)
+    for path in ("walker", "jit"):              # "jit": 1023 nodes, so the compiled distance program
+        rgba_w, hit_w, _ = gpu_render(table, w, h, info, path)
+        assert np.array_equal(rgba_w, rgba) and np.array_equal(hit_w, hit), path
 
 
 @pytest.mark.parametrize("name", ["mixed_kinds", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
-@pytest.mark.parametrize("path", ["jit", "program"])
+@pytest.mark.parametrize("path", ["jit", "jitprog", "program"])
 def test_kat_scene_frames(name, path):
     """Whole frames of the nested test scenes (LDS value slots, saved frames, bounding spheres)."""
     table = kat_scenes.tables()[name]

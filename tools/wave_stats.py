@@ -12,6 +12,7 @@ from raytracing_amd import api
 
 scene, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 nodes = api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
+if os.environ.get("RM_JIT"): print("RM_JIT", os.environ["RM_JIT"])
 with api.Raymarching(w, h) as rm:
     rm.set_nodes(nodes)
     rm.set_info(O.default_info(1, 0))
