@@ -50,6 +50,9 @@ WORKLOADS = {
     "infinity_4k": ("infinity", 3840, 2160),
     "csg1024_4k": ("csg1024", 3840, 2160),
     "chair_8k": ("chair", 7680, 4320),
+    # BASELINE.json configs[4]: the 120-frame camera sweep (tests/golden/sweep_rays_info.bin: frame k =
+    # k+1 light rotations of 1 degree and a right-button drag of k pixels, Source/main.cpp:248-266)
+    "chair_8k_sweep": ("chair", 7680, 4320),
 }
 
 
@@ -141,7 +144,10 @@ def main():
     scene, w, h = WORKLOADS[args.workload]
     nodes = load_nodes(scene)
     info = O.default_info(1, 0)          # main.cpp default camera, light at +1 degree ("frame 0")
-    want = golden_frame(scene, w, h)
+    sweep = None
+    if args.workload.endswith("_sweep"):
+        sweep = np.fromfile(os.path.join(ROOT, "tests", "golden", "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
+    want = None if sweep is not None else golden_frame(scene, w, h)
     in_flight = args.in_flight or (1 if world == 1 else 3)
 
     # one context per frame in flight, each on a stream of its own
@@ -183,7 +189,7 @@ def main():
     def step(k):
         j = k % in_flight
         rm = ctxs[j]
-        rm.set_info(info)
+        rm.set_info(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
         if world == 1:
             rm.process_async()
             return

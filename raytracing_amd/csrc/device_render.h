@@ -172,7 +172,16 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             mode = M_DONE;
         };
         auto shadow_tail = [&]() {                                                 // :679-690
-            shadow = min2(shadow, RM_HARDNESS * cd / t);
+            // shadow = min(shadow, (128*cd)/t).  The quotient matters only when it is below `shadow`, and
+            // most steps it is not: n > shadow*t, by a margin that covers the product's rounding, means
+            // n/t > shadow in exact arithmetic, so the rounded quotient is >= shadow and min() keeps
+            // `shadow` bit for bit.  Only the other lanes pay for the division (12 instructions).
+            const float n = RM_HARDNESS * cd, st = shadow * t;
+            if (!(n > st + fabsf(st) * 4.8e-7f)) {
+                float ns = n;
+                asm volatile("; shadow quotient" : "+v"(ns));           // a branch, not a select over a speculated division
+                shadow = min2(shadow, ns / t);
+            }
             if (shadow < 0.01f) { finish(); return; }
             pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
             t += cd;
