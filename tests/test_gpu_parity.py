@@ -353,3 +353,19 @@ def test_8k_frame_rows(stock_scenes, golden_dir):
             rm.process()
             parts.append(rm.read_pixels())
         assert np.array_equal(tiling.assemble(parts, h, 16), whole)
+
+
+@pytest.mark.parametrize("name", ["chair", "infinity"])
+def test_front_end_ppm_matches_reference_hash(name, golden_dir, tmp_path):
+    """The headless front end with the reference's command line (Source/main.cpp:18-39) and default
+    camera writes the PPM whose sha256 the reference's own march produced host-side."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / (name + ".ppm"))
+    exe = os.path.join(root, "raytracing_amd", "rm_render")
+    run = subprocess.run([exe, "--width", "640", "--height", "480", "--input",
+                          os.path.join(golden_dir, "scenes", name + ".sce"), "--out", out],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr + run.stdout
+    with open(out, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == GOLDEN_PPM[name]
