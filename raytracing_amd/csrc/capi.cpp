@@ -201,7 +201,8 @@ hipError_t exact_divisors(rm_ctx* c, const rm_node* nodes, size_t n, rm::Divisor
 bool jit_source(const rm_node* nodes, size_t n, const rm::SceneBuild& built, const rm::DivisorSet* exact,
                 bool force_program, std::string* src, size_t* lds_bytes) {
     if (built.reachable <= rm::kJitMaxNodes && !force_program) {
-        *src = rm::generate_scene_source(nodes, n, built.seen.data(), exact);
+        *src = rm::generate_scene_source(nodes, n, built.seen.data(), exact,
+                                         built.program.size() <= rm::kJitMaxSlots ? &built.program : nullptr, built.value_slots);
         *lds_bytes = 0;
         return true;
     }

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
     const uint32_t w0 = w[0], op = w0 & 0xff, slot = w0 >> F_SLOT_SHIFT;
     const P3 S = SRC_F ? m.F : m.P;
     const float f1 = as_f(w[1]), f2 = as_f(w[2]), f3 = as_f(w[3]), f4 = as_f(w[4]),
-                f5 = as_f(w[5]), f6 = as_f(w[6]), f7 = as_f(w[7]);
+                f5 = as_f(w[5]), f6 = as_f(w[6]);
     // -inf continues a min chain, +inf a max chain
     const float sel = as_f((w0 & (COMB_MAX << F_COMB_SHIFT)) ? 0x7f800000u : 0xff800000u);
     const uint32_t sign = (w0 & F_NEG) ? 0x80000000u : 0u;
@@ -102,7 +102,7 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
         break;
     }
     case OP_CULL:                  // scene_program.h; lanes that do not march have no say
-        if (cull_all(S, m.A, active, f1, f2, f3, f4)) skip = w[5];
+        if (cull_all(S, (w0 & F_NEG) ? -m.A : m.A, active, f1, f2, f3, f4)) skip = w[5];
         break;
     case OP_PORTANTA_END: {
         float d = stack[slot * RM_BLOCK_THREADS];
@@ -371,6 +371,11 @@ struct InterpScene {
         return evaluator == 0 ? run_program(program, p, stack, active) : walk_dist(tree, 0, p, st, 0);
     }
     __device__ __forceinline__ P3 norm(P3 p, Scratch& st) { return walk_norm(tree, 0, p, st); }
+    // What the normal may re-use of the distance just evaluated at the same point: nothing here
+    // (the generated scenes of jit.cpp keep their transformed points and child distances).
+    struct Keep {};
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch& st, bool active, Keep&) { return dist(p, st, active); }
+    __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return norm(p, st); }
 };
 
 }  // namespace rm

@@ -75,9 +75,13 @@ __device__ __forceinline__ float sfero_dist(P3 q, float r) { return length_3(q.x
 
 __device__ __forceinline__ float kubo_dist(P3 p, float bx, float by, float bz) {
     float qx = fabsf(p.x) - bx, qy = fabsf(p.y) - by, qz = fabsf(p.z) - bz;
-    float inside = max2(qx, max2(qy, qz));
-    float outside = length_3(max2(qx, 0.f), max2(qy, 0.f), max2(qz, 0.f));
-    return (qx < 0.f && qy < 0.f && qz < 0.f) ? inside : outside;
+    // The reference's max() is a compare and a select; v_max_f32 / v_max3_f32 differ from that only
+    // in the sign of a zero result (and for NaN, which finite positions never produce).  The clamps
+    // are squared, which drops the sign.  `inside` is used only where all three are negative: no
+    // zero among them, and "all three negative" is "their maximum is negative" (-0 is not).
+    float inside = __builtin_fmaxf(__builtin_fmaxf(qx, qy), qz);
+    float outside = length_3(__builtin_fmaxf(qx, 0.f), __builtin_fmaxf(qy, 0.f), __builtin_fmaxf(qz, 0.f));
+    return inside < 0.f ? inside : outside;
 }
 
 __device__ __forceinline__ float cilindro_dist(P3 p, float r, float h) {

@@ -213,38 +213,41 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             if (trips > prm.boost_age && !boosted) { __builtin_amdgcn_s_setprio(3); boosted = true; }
 
             const bool active = (mode != M_DONE) && !need;
-            const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);
-            if (amask != 0) {
-                ++st_evals;
-                // DIST(root, pos) for the whole wave (:627 and :661 share this)
-                float d = scene.dist(pos, scratch, active);
-                if (active) {
-                    cd = d;
-                    if (mode == M_PRIMARY) {
-                        if (cd < RM_MIN_DIST) {                                    // :629
-                            if (cd < -0.f) primary_normal(P3{-rd.x, -rd.y, -rd.z});  // :630-633
-                            else need = true;
-                        } else {
-                            advance_primary();
-                        }
+            if (__builtin_amdgcn_ballot_w64(active) == 0) break;      // no lane waits for a normal here (below)
+            ++st_evals;
+            // DIST(root, pos) for the whole wave (:627 and :661 share this)
+            const P3 at = pos;
+            typename Scene::Keep keep;
+            float d = scene.dist_keep(at, scratch, active, keep);
+            if (active) {
+                cd = d;
+                if (mode == M_PRIMARY) {
+                    if (cd < RM_MIN_DIST) {                                    // :629
+                        if (cd < -0.f) primary_normal(P3{-rd.x, -rd.y, -rd.z});  // :630-633
+                        else need = true;
                     } else {
-                        if (8 * cd < RM_MIN_DIST) {                                // :662
-                            if (cd < -0.f) shadow_normal(P3{-light.x, -light.y, -light.z});   // :663-666
-                            else need = true;
-                        } else {
-                            shadow_tail();
-                        }
+                        advance_primary();
+                    }
+                } else {
+                    if (8 * cd < RM_MIN_DIST) {                                // :662
+                        if (cd < -0.f) shadow_normal(P3{-light.x, -light.y, -light.z});   // :663-666
+                        else need = true;
+                    } else {
+                        shadow_tail();
                     }
                 }
             }
+            // Lanes that reached a surface take their normal in the same trip, at the point the
+            // distance was just evaluated at (a waiting lane does not move): the normal's transforms
+            // and child distances are the ones computed above, and the compiler shares them.
             const unsigned long long nmask = __builtin_amdgcn_ballot_w64(need);
+            if (nmask == 0) continue;
             const unsigned long long run = __builtin_amdgcn_ballot_w64((mode != M_DONE) && !need);
-            if (nmask == 0) { if (run == 0) break; continue; }
             if (run != 0 && (uint32_t)__builtin_popcountll(nmask) < prm.norm_batch) continue;
             const uint64_t st_n0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
             ++st_norms;
             if (need) {                                                            // :635-637, :668-670
-                P3 N = scene.norm(pos, scratch);
+                P3 N = scene.norm_keep(at, scratch, keep);
                 float R_1 = r_length_3(N.x, N.y, N.z);
                 P3 n{R_1 * N.x, R_1 * N.y, R_1 * N.z};
                 if (mode == M_PRIMARY) primary_normal(n); else shadow_normal(n);

@@ -60,11 +60,12 @@ rm_eval_points_jit(const rm::RenderParams prm, const float* __restrict__ xyz, ui
     const bool live = i < count;
     rm::P3 p{0.f, 0.f, 0.f};
     if (live) p = rm::P3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
-    const float d = scene.dist(p, scratch, live);          // wave-uniform code: every lane runs it
+    rm::JitScene::Keep keep;
+    const float d = scene.dist_keep(p, scratch, live, keep);          // wave-uniform code: every lane runs it
     if (live) {
         dist_out[i] = d;
         if (norm_out) {
-            rm::P3 N = scene.norm(p, scratch);
+            rm::P3 N = scene.norm_keep(p, scratch, keep);
             norm_out[3 * i] = N.x; norm_out[3 * i + 1] = N.y; norm_out[3 * i + 2] = N.z;
         }
     }
@@ -76,9 +77,195 @@ uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
     return h;
 }
 
+
+// -----------------------------------------------------------------------------
+// Distance and normal of a small scene as ONE pair of functions over named
+// temporaries: the march evaluates the distance every trip, and a lane that then
+// needs its normal (Source/cuda_kernels.cu:635, :668) needs it at the same point.
+// The normal re-uses the transformed points and the child distances the distance
+// pass just computed (struct SceneKeep, registers after inlining) and adds only
+// its own selects, the leaf's normal and the rotations back.  The separate
+// n<i>(p) functions recompute all of that; they remain for sub-trees behind a
+// portanta_sfero, whose distance is evaluated only near its sphere.
+// Inner min/max are v_med3 against an infinity as in the distance program: they
+// differ from the reference's compare-and-select only in the sign of a zero,
+// which no comparison, glata_h or later arithmetic turns into another value.
+// -----------------------------------------------------------------------------
+struct Fused {
+    const rm_node* nodes;
+    const DivisorSet* exact;
+    std::string decl, dist, norm;
+    int counter = 0;
+    std::map<std::pair<size_t, std::string>, std::string> dmemo, pmemo;
+    Fused(const rm_node* nodes_, const DivisorSet* exact_) : nodes(nodes_), exact(exact_) {}
+
+    std::string new_f() { std::string v = "d" + std::to_string(counter++); decl += "    float " + v + ";\n"; return "k." + v; }
+    std::string new_p() { std::string v = "p" + std::to_string(counter++); decl += "    P3 " + v + ";\n"; return "k." + v; }
+    size_t kid(size_t i, int k) const { return i + static_cast<size_t>(nodes[i].o[k]); }
+    static bool is_min(uint32_t t) { return t == RM_TYPE_KUNIGAJO_2 || t == RM_TYPE_KUNIGAJO_3 || t == RM_TYPE_KUNIGAJO_4; }
+
+    std::string qlit(const rm_node& nd) {
+        float Q[9]; build_q(nd, Q);
+        std::string q;
+        for (int k = 0; k < 9; ++k) q += (k ? ", " : "") + lit(Q[k]);
+        return q;
+    }
+
+    // the point node i hands to its child, for i a transform (or a portanta_sfero)
+    std::string point(size_t i, const std::string& pv) {
+        const auto key = std::make_pair(i, pv);
+        auto it = pmemo.find(key);
+        if (it != pmemo.end()) return it->second;
+        const rm_node& nd = nodes[i];
+        const std::string q = new_p();
+        std::string e;
+        switch (nd.type) {
+        case RM_TYPE_MOVO: case RM_TYPE_PORTANTA_SFERO: e = "movo(" + pv + ", " + lit3(nd.f) + ")"; break;
+        case RM_TYPE_ROTACIOX: e = "rotx(" + pv + ", " + lit(nd.f[0]) + ", " + lit(nd.f[1]) + ")"; break;
+        case RM_TYPE_ROTACIOY: e = "roty(" + pv + ", " + lit(nd.f[0]) + ", " + lit(nd.f[1]) + ")"; break;
+        case RM_TYPE_ROTACIOZ: e = "rotz(" + pv + ", " + lit(nd.f[0]) + ", " + lit(nd.f[1]) + ")"; break;
+        case RM_TYPE_ROTACIOQ: e = "rotq(" + pv + ", " + qlit(nd) + ")"; break;
+        default: {                              // senfina_ripeto
+            const float aa = ripeto_aa(nd);
+            e = "ripeto(" + pv + ", " + lit3(nd.f) + ", " + lit(aa) + ", " + lit(divisor_reciprocal(exact, aa)) + ")";
+        }
+        }
+        dist += "    " + q + " = " + e + ";\n";
+        pmemo[key] = q;
+        return q;
+    }
+
+    std::string d(size_t i, const std::string& pv) {
+        const auto key = std::make_pair(i, pv);
+        auto it = dmemo.find(key);
+        if (it != dmemo.end()) return it->second;
+        const rm_node& nd = nodes[i];
+        std::string v;
+        auto leaf = [&](const std::string& call) { v = new_f(); dist += "    " + v + " = " + call + ";\n"; };
+        switch (nd.type) {
+        case RM_TYPE_SFERO:    leaf("sfero_dist(" + pv + ", " + lit(nd.f[0]) + ")"); break;
+        case RM_TYPE_KUBO:     leaf("kubo_dist(" + pv + ", " + lit3(nd.f) + ")"); break;
+        case RM_TYPE_CILINDRO: leaf("cilindro_dist(" + pv + ", " + lit(nd.f[0]) + ", " + lit(nd.f[1]) + ")"); break;
+        case RM_TYPE_EBENO:    leaf("ebeno_dist(" + pv + ", " + lit3(nd.f) + ")"); break;
+        case RM_TYPE_PORTANTA_SFERO: {
+            const std::string q = point(i, pv);
+            leaf("length_3(" + q + ".x, " + q + ".y, " + q + ".z) - " + lit(nd.f[3]));
+            dist += "    if (" + v + " <= RM_MIN_DIST) " + v + " = " + fn('d', kid(i, 0)) + "(" + q + ");\n";
+            break;
+        }
+        case RM_TYPE_KOMPLEMENTO: { const std::string a = d(kid(i, 0), pv); leaf("-" + a); break; }
+        case RM_TYPE_MOVO: case RM_TYPE_SENFINA_RIPETO: case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY:
+        case RM_TYPE_ROTACIOZ: case RM_TYPE_ROTACIOQ:
+            v = d(kid(i, 0), point(i, pv));
+            break;
+        case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: {
+            const std::string a = d(kid(i, 0), pv), b = d(kid(i, 1), pv);
+            leaf("glata(" + a + ", " + b + ", " + lit(nd.f[0]) + ", " + lit(divisor_reciprocal(exact, nd.f[0])) + ", " +
+                 (nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? "true" : "false") + ")");
+            break;
+        }
+        default: {                              // kunigajo_N / komunajo_N
+            const int na = node_arity(nd.type);
+            const std::string sel = is_min(nd.type) ? "as_f(0xff800000u)" : "as_f(0x7f800000u)";
+            std::vector<std::string> a;
+            for (int c = 0; c < na; ++c) a.push_back(d(kid(i, c), pv));
+            std::string e = a[0];
+            for (int c = 1; c < na; ++c) e = "__builtin_amdgcn_fmed3f(" + e + ", " + a[static_cast<size_t>(c)] + ", " + sel + ")";
+            leaf(e);
+        }
+        }
+        dmemo[key] = v;
+        return v;
+    }
+
+    // statements that leave NORM(node i, pv) in `out`
+    void n(size_t i, const std::string& pv, const std::string& out, int depth) {
+        const std::string pad(static_cast<size_t>(depth) * 4, ' ');
+        const rm_node& nd = nodes[i];
+        switch (nd.type) {
+        case RM_TYPE_SFERO:    norm += pad + out + " = " + pv + ";\n"; break;
+        case RM_TYPE_KUBO:     norm += pad + out + " = kubo_norm(" + pv + ", " + lit3(nd.f) + ");\n"; break;
+        case RM_TYPE_CILINDRO: norm += pad + out + " = cilindro_norm(" + pv + ", " + lit(nd.f[0]) + ", " + lit(nd.f[1]) + ");\n"; break;
+        case RM_TYPE_EBENO:    norm += pad + out + " = P3{" + lit3(nd.f) + "};\n"; break;
+        case RM_TYPE_PORTANTA_SFERO:
+            norm += pad + out + " = " + fn('n', kid(i, 0)) + "(" + point(i, pv) + ");\n";
+            break;
+        case RM_TYPE_KOMPLEMENTO:
+            n(kid(i, 0), pv, out, depth);
+            norm += pad + out + " = neg3(" + out + ");\n";
+            break;
+        case RM_TYPE_MOVO: case RM_TYPE_SENFINA_RIPETO:
+            n(kid(i, 0), point(i, pv), out, depth);
+            break;
+        case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY: case RM_TYPE_ROTACIOZ: {
+            const char* ax = nd.type == RM_TYPE_ROTACIOX ? "x" : nd.type == RM_TYPE_ROTACIOY ? "y" : "z";
+            n(kid(i, 0), point(i, pv), out, depth);
+            norm += pad + out + " = rot" + ax + "_back(" + out + ", " + lit(nd.f[0]) + ", " + lit(nd.f[1]) + ");\n";
+            break;
+        }
+        case RM_TYPE_ROTACIOQ:
+            n(kid(i, 0), point(i, pv), out, depth);
+            norm += pad + out + " = rotq_back(" + out + ", " + qlit(nd) + ");\n";
+            break;
+        case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: {
+            const std::string a = d(kid(i, 0), pv), b = d(kid(i, 1), pv), id = std::to_string(counter++);
+            const std::string h = "h" + id, na = "na" + id, nb = "nb" + id;
+            norm += pad + "const float " + h + " = glata_h(" + a + ", " + b + ", " + lit(nd.f[0]) + ", " +
+                    lit(divisor_reciprocal(exact, nd.f[0])) + ", " + (nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? "true" : "false") + ");\n";
+            norm += pad + "if (" + h + " > 1.f) {\n";
+            n(kid(i, 0), pv, out, depth + 1);
+            norm += pad + "} else if (" + h + " < 0.f) {\n";
+            n(kid(i, 1), pv, out, depth + 1);
+            norm += pad + "} else {\n" + pad + "    P3 " + na + ", " + nb + ";\n";
+            n(kid(i, 0), pv, na, depth + 1);
+            n(kid(i, 1), pv, nb, depth + 1);
+            norm += pad + "    " + out + " = glata_blend(" + na + ", " + nb + ", " + h + ");\n" + pad + "}\n";
+            break;
+        }
+        default: {                              // kunigajo_N / komunajo_N
+            const int na = node_arity(nd.type);
+            const bool mn = is_min(nd.type);
+            std::vector<std::string> a;
+            for (int c = 0; c < na; ++c) a.push_back(d(kid(i, c), pv));
+            if (na == 2) {                      // ties go to child 1 (:153, :252)
+                norm += pad + "if (" + a[0] + (mn ? " < " : " > ") + a[1] + ") {\n";
+                n(kid(i, 0), pv, out, depth + 1);
+                norm += pad + "} else {\n";
+                n(kid(i, 1), pv, out, depth + 1);
+                norm += pad + "}\n";
+            } else {                            // ties go to the earlier child (:179,186 ... :316,323,330)
+                const std::string id = std::to_string(counter++), best = "best" + id, pick = "pick" + id;
+                norm += pad + "float " + best + " = " + a[0] + "; int " + pick + " = 0;\n";
+                for (int c = 1; c < na; ++c)
+                    norm += pad + "if (" + best + (mn ? " > " : " < ") + a[static_cast<size_t>(c)] + ") { " + best + " = " +
+                            a[static_cast<size_t>(c)] + "; " + pick + " = " + std::to_string(c) + "; }\n";
+                for (int c = 0; c < na; ++c) {
+                    norm += pad + (c == 0 ? "if (" + pick + " == 0) {\n"
+                                   : c + 1 < na ? "} else if (" + pick + " == " + std::to_string(c) + ") {\n" : "} else {\n");
+                    n(kid(i, c), pv, out, depth + 1);
+                }
+                norm += pad + "}\n";
+            }
+        }
+        }
+    }
+
+    std::string source() {
+        const std::string root = d(0, "E");
+        n(0, "E", "N", 1);
+        return "struct SceneKeep {\n" + decl + "};\n"
+               "__device__ __forceinline__ float scene_dist_keep(P3 E, SceneKeep& k) {\n" + dist + "    return " + root + ";\n}\n"
+               "__device__ __forceinline__ P3 scene_norm_keep(P3 E, const SceneKeep& k) {\n    P3 N{0.f, 0.f, 0.f};\n" + norm +
+               "    (void)E; (void)k;\n    return N;\n}\n";
+    }
+};
+
 }  // namespace
 
-std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen, const DivisorSet* exact) {
+namespace { std::string program_function(const std::vector<Slot>& program, uint32_t value_slots); }
+
+std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen, const DivisorSet* exact,
+                                  const std::vector<Slot>* program, uint32_t value_slots) {
     std::string s = "namespace rm {\n";
     const std::string FD = "__device__ __forceinline__ float ", FN = "__device__ __forceinline__ P3 ";
     // children carry higher indices than their parents (links point forward), so
@@ -173,16 +360,39 @@ std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned
         }
         }
     }
-    s += R"(
+    // A scene whose distance program holds bounding-sphere tests (scene_program.h, OP_CULL) marches on
+    // the compiled program and takes normals from n0; every other one uses the fused pair above.
+    bool culls = false;
+    if (program)
+        for (const Slot& sl : *program) culls = culls || (sl.w[0] & 0xff) == OP_CULL;
+    if (culls) {
+        s += program_function(*program, value_slots);
+        s += R"(
 struct JitScene {
     struct Scratch {};
+    struct Keep {};
     __device__ __forceinline__ void init(const RenderParams&) {}
-    __device__ __forceinline__ float dist(P3 p, Scratch&, bool) { return d0(p); }
-    __device__ __forceinline__ P3 norm(P3 p, Scratch&) { return n0(p); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
+    __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep&) { return n0(p); }
 };
 }  // namespace rm
 
 )";
+    } else {
+        Fused fused(nodes, exact);
+        s += fused.source();
+        s += R"(
+struct JitScene {
+    struct Scratch {};
+    typedef SceneKeep Keep;
+    __device__ __forceinline__ void init(const RenderParams&) {}
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool, Keep& k) { return scene_dist_keep(p, k); }
+    __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep& k) { return scene_norm_keep(p, k); }
+};
+}  // namespace rm
+
+)";
+    }
     s += kJitKernels;
     return s;
 }
@@ -201,7 +411,9 @@ std::string slot_f(const Slot& sl, int k) { float v; std::memcpy(&v, &sl.w[k], 4
 
 // ranks != nullptr: selection mode (generate_program_source, scene_norm): a primitive slot also
 // records itself in `best` if it lowers A, or equals it and outranks the holder
-void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string& s, int indent,
+// a_inf: A is known to hold +inf here (function entry, after a push): the first member of a min
+// chain is then assigned, not combined (med3(+inf, v, -inf) is v; the compiler keeps a v_max for it).
+void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string& s, int indent, bool& a_inf,
                 const std::vector<int32_t>* slot_node = nullptr, const std::vector<uint32_t>* ranks = nullptr) {
     const std::string pad(static_cast<size_t>(indent) * 4, ' ');
     for (size_t pc = lo; pc < hi; ++pc) {
@@ -215,7 +427,13 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
         const std::string V = "s" + std::to_string(slot);
         const std::string to_f = (w0 & F_DST_F) ? " F = P;" : "";
         auto prim = [&](const std::string& call) {
-            if (!ranks) { s += pad + "A = __builtin_amdgcn_fmed3f(A, " + neg + call + ", " + sel + ");\n"; return; }
+            if (!ranks) {
+                const bool is_min = !(w0 & (COMB_MAX << F_COMB_SHIFT));
+                if (a_inf && is_min) s += pad + "A = " + neg + call + ";\n";
+                else s += pad + "A = __builtin_amdgcn_fmed3f(A, " + neg + call + ", " + sel + ");\n";
+                a_inf = false;
+                return;
+            }
             const std::string rk = std::to_string((*ranks)[static_cast<size_t>((*slot_node)[pc])]) + "u";
             s += pad + "{ const float v = " + neg + call + "; const bool take = v < A || (v == A && " + rk + " > brank); " +
                  "A = take ? v : A; best = take ? " + std::to_string(pc) + "u : best; brank = take ? " + rk + " : brank; }\n";
@@ -240,13 +458,13 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
         case OP_KUBO:    prim("kubo_dist(" + moved + ", " + f4 + ", " + f5 + ", " + f6 + ")"); break;
         case OP_CILINDRO:prim("cilindro_dist(" + moved + ", " + f4 + ", " + f5 + ")"); break;
         case OP_EBENO:   prim("ebeno_dist(" + moved + ", " + f4 + ", " + f5 + ", " + f6 + ")"); break;
-        case OP_PUSHA_R: s += pad + "B = A; A = __builtin_inff();\n"; break;
-        case OP_POPC_R:  s += pad + "A = __builtin_amdgcn_fmed3f(B, A, " + sel + ");\n"; break;
-        case OP_PUSHA:   s += pad + V + " = A; A = __builtin_inff();\n"; break;
-        case OP_POPC:    s += pad + "A = __builtin_amdgcn_fmed3f(" + V + ", A, " + sel + ");\n"; break;
-        case OP_NEG:     s += pad + "A = -A;\n"; break;
-        case OP_GLATA_R: s += pad + "A = glata(B, A, " + f1 + ", " + f2 + ", " + ((w0 & F_NEG) ? "true" : "false") + ");\n"; break;
-        case OP_GLATA:   s += pad + "A = glata(" + V + ", A, " + f1 + ", " + f2 + ", " + ((w0 & F_NEG) ? "true" : "false") + ");\n"; break;
+        case OP_PUSHA_R: s += pad + "B = A; A = __builtin_inff();\n"; a_inf = true; break;
+        case OP_POPC_R:  s += pad + "A = __builtin_amdgcn_fmed3f(B, A, " + sel + ");\n"; a_inf = false; break;
+        case OP_PUSHA:   s += pad + V + " = A; A = __builtin_inff();\n"; a_inf = true; break;
+        case OP_POPC:    s += pad + "A = __builtin_amdgcn_fmed3f(" + V + ", A, " + sel + ");\n"; a_inf = false; break;
+        case OP_NEG:     s += pad + "A = -A;\n"; a_inf = false; break;
+        case OP_GLATA_R: s += pad + "A = glata(B, A, " + f1 + ", " + f2 + ", " + ((w0 & F_NEG) ? "true" : "false") + ");\n"; a_inf = false; break;
+        case OP_GLATA:   s += pad + "A = glata(" + V + ", A, " + f1 + ", " + f2 + ", " + ((w0 & F_NEG) ? "true" : "false") + ");\n"; a_inf = false; break;
         case OP_PUSHF:
             s += pad + V + " = F.x; s" + std::to_string(slot + 1) + " = F.y; s" + std::to_string(slot + 2) + " = F.z; F = P;\n";
             break;
@@ -257,18 +475,20 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
             const size_t skip = sl.w[5];
             s += pad + "P = " + moved + "; " + V + " = length_3(P.x, P.y, P.z) - " + f4 + ";\n";
             s += pad + "if (__builtin_amdgcn_ballot_w64(" + V + " <= RM_MIN_DIST) != 0) {\n";
-            emit_range(prog, pc + 1, pc + 1 + skip, s, indent + 1, slot_node, ranks);
+            emit_range(prog, pc + 1, pc + 1 + skip, s, indent + 1, a_inf, slot_node, ranks);
             s += pad + "}\n";
             pc += skip;
+            a_inf = false;
             break;
         }
-        case OP_PORTANTA_END: s += pad + "A = (" + V + " <= RM_MIN_DIST) ? A : " + V + ";\n"; break;
+        case OP_PORTANTA_END: s += pad + "A = (" + V + " <= RM_MIN_DIST) ? A : " + V + ";\n"; a_inf = false; break;
         case OP_CULL: {                // scene_program.h
             const size_t skip = sl.w[5];
-            s += pad + "if (!cull_all(" + S + ", A, active, " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ")) {\n";
-            emit_range(prog, pc + 1, pc + 1 + skip, s, indent + 1, slot_node, ranks);
+            s += pad + "if (!cull_all(" + S + ", " + ((w0 & F_NEG) ? "-A" : "A") + ", active, " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ")) {\n";
+            emit_range(prog, pc + 1, pc + 1 + skip, s, indent + 1, a_inf, slot_node, ranks);
             s += pad + "}\n";
             pc += skip;
+            a_inf = false;          // the range may or may not have run
             break;
         }
         default: break;
@@ -276,20 +496,25 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
     }
 }
 
-}  // namespace
-
-std::string generate_program_source(const std::vector<Slot>& program, uint32_t value_slots,
-                                    const std::vector<int32_t>& slot_node, const std::vector<uint32_t>& union_rank) {
-    std::string s = "namespace rm {\n";
-    s += "__device__ __forceinline__ float scene_program(P3 E, bool active) {\n";
+std::string program_function(const std::vector<Slot>& program, uint32_t value_slots) {
+    std::string s = "__device__ __forceinline__ float scene_program(P3 E, bool active) {\n";
     s += "    P3 F = E, P = E; float A = __builtin_inff(), B = 0.f, tx = 0.f, ty = 0.f;\n";
     if (value_slots) {
         s += "    float";
         for (uint32_t k = 0; k < value_slots; ++k) s += std::string(k ? "," : "") + " s" + std::to_string(k) + " = 0.f";
         s += ";\n";
     }
-    emit_range(program, 0, program.size(), s, 1);
-    s += "    (void)B; (void)tx; (void)ty; (void)F; (void)P;\n    return A;\n}\n";
+    bool a_inf = true;
+    emit_range(program, 0, program.size(), s, 1, a_inf);
+    s += "    (void)B; (void)tx; (void)ty; (void)F; (void)P; (void)active;\n    return A;\n}\n";
+    return s;
+}
+
+}  // namespace
+
+std::string generate_program_source(const std::vector<Slot>& program, uint32_t value_slots,
+                                    const std::vector<int32_t>& slot_node, const std::vector<uint32_t>& union_rank) {
+    std::string s = "namespace rm {\n" + program_function(program, value_slots);
 
     if (union_rank.empty()) {
         // normals by the tree walker over the LDS tree table: a normal function per node would
@@ -303,8 +528,9 @@ struct JitScene {
         tree = reinterpret_cast<const TreeNode*>(lds);
         stage_tree(prm.tree, prm.n_nodes, lds);
     }
-    __device__ __forceinline__ float dist(P3 p, Scratch&, bool active) { return scene_program(p, active); }
-    __device__ __forceinline__ P3 norm(P3 p, Scratch& st) { return walk_norm(tree, 0, p, st); }
+    struct Keep {};
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
+    __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return walk_norm(tree, 0, p, st); }
 };
 }  // namespace rm
 )";
@@ -320,7 +546,8 @@ struct JitScene {
     s += "__device__ __forceinline__ P3 scene_norm(P3 E) {\n";
     s += "    const bool active = true;     // called by the lanes that need a normal: the others are masked off\n";
     s += "    P3 F = E, P = E; float A = __builtin_inff(), tx = 0.f, ty = 0.f; uint32_t best = 0u, brank = 0u;\n";
-    emit_range(program, 0, program.size(), s, 1, &slot_node, &union_rank);
+    bool a_inf = true;
+    emit_range(program, 0, program.size(), s, 1, a_inf, &slot_node, &union_rank);
     s += "    (void)tx; (void)ty; (void)P; (void)brank;\n    P3 N{0.f, 0.f, 0.f};\n    switch (best) {\n";
     std::vector<std::string> back;            // rotations met on the way down, to undo on the way up
     for (size_t pc = 0; pc < program.size(); ++pc) {
@@ -354,8 +581,9 @@ struct JitScene {
 struct JitScene {
     struct Scratch {};
     __device__ __forceinline__ void init(const RenderParams&) {}
-    __device__ __forceinline__ float dist(P3 p, Scratch&, bool active) { return scene_program(p, active); }
-    __device__ __forceinline__ P3 norm(P3 p, Scratch&) { return scene_norm(p); }
+    struct Keep {};
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
+    __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep&) { return scene_norm(p); }
 };
 }  // namespace rm
 )";

@@ -39,7 +39,10 @@ struct JitKernels {
 
 // HIP source of the d<i>/n<i> function pairs of every reachable node plus the
 // kernels built on them.  `seen[i]` marks reachable nodes (scene_build).
-std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen, const DivisorSet* exact = nullptr);
+// With `program` (the flattened distance program) the march evaluates that, compiled slot by slot
+// with its culls, and the per-node d<i> serve the normal functions only.
+std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned char* seen, const DivisorSet* exact = nullptr,
+                                  const std::vector<Slot>* program = nullptr, uint32_t value_slots = 0);
 
 // The same kernels from the flattened distance program of a large scene.
 // slot_node / union_rank: SceneBuild's; with a non-empty union_rank normals come from one pass over

@@ -575,9 +575,21 @@ struct Flattener {
         if (err) return;
         if (!check_chain(idx)) return;
         if (try_prim(idx, SRC_F, comb)) return;
-        const long cull_at = begin_cull(idx, comb);
+        const long cull_at = comb == COMB_MAX ? begin_cull_max(idx) : begin_cull(idx, comb);
         accum_body(idx, comb);
         end_cull(cull_at);
+    }
+    // The same test for a max chain (intersection): a member komplemento(X) with X inside a sphere
+    // (c, r) is at most r - |F - c| (X's distance is at least |F - c| - r), so where that is below
+    // the running maximum A for every marching lane, max() would return A.  The slot carries
+    // F_NEG: the device applies the min-chain test to -A.
+    long begin_cull_max(size_t idx) {
+        if (!cull || idx >= n || nodes[idx].type != RM_TYPE_KOMPLEMENTO || nodes[idx].o[0] <= 0) return -1;
+        Bound b = bound_of(idx + static_cast<size_t>(nodes[idx].o[0]));
+        if (!b.ok || b.leaves < 3) return -1;      // the test costs about one sphere: measured no gain on chair.sce's pair
+        const long at = emit_cull(b);
+        prog[static_cast<size_t>(at)].w[0] |= F_NEG;
+        return at;
     }
     void accum_body(size_t idx, uint32_t comb) {
         const uint32_t ty = idx < n ? nodes[idx].type : 0;

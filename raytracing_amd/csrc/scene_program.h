@@ -95,6 +95,8 @@ enum Op : uint32_t {
     // coordinates).  If for every lane that still marches |F - c| - r exceeds A by a margin that
     // covers every rounding error (w4 = r + margin, see scene_build.cpp), min() would return A
     // bit for bit, and the slots are skipped.
+    // With F_NEG the chain is a max chain and the sub-tree is komplemento(X), X inside the sphere:
+    // it is at most r - |F - c|, and the same test runs on -A.
     OP_CULL,          // w1-3 c, w4 r + margin, w5 skip
     OP_COUNT
 };

@@ -46,6 +46,8 @@ SCENES = {
                         ("kunigajo_3", (), ("movo", (-6, 0, 0), S5), ("movo", (0, 7, 0), C34), ("movo", (0, 0, -8), S5))),
     "mixed_kinds": ("komunajo_2", (), ("kunigajo_2", (), ("movo", (2, 0, 0), S5), K345),
                     ("komplemento", (), ("kunigajo_2", (), ("movo", (0, 0, -3), ("sfero", (2,))), ("movo", (0, 0, 3), ("sfero", (1.5,)))))),
+    "carved": ("komunajo_2", (), ("kubo", (6, 6, 6)),
+               ("komplemento", (), ("kunigajo_3", (), ("movo", (5, 5, 0), S5), ("movo", (-6, 0, 4), ("sfero", (3,))), ("movo", (0, -6, 0), C34)))),
     "nested_frames": ("kunigajo_2", (),
                       ("movo", (3, 0, 0), ("komunajo_2", (), K345,
                                            ("rotacioX", (COS, SIN), ("kunigajo_2", (), S5, ("movo", (0, 4, 0), ("sfero", (3,))))))),

@@ -165,7 +165,7 @@ def test_csg1024_frame():
         assert np.array_equal(rgba_w, rgba) and np.array_equal(hit_w, hit), path
 
 
-@pytest.mark.parametrize("name", ["mixed_kinds", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
+@pytest.mark.parametrize("name", ["mixed_kinds", "carved", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
 @pytest.mark.parametrize("path", ["jit", "jitprog", "program"])
 def test_kat_scene_frames(name, path):
     """Whole frames of the nested test scenes (LDS value slots, saved frames, bounding spheres)."""

@@ -152,6 +152,16 @@ def test_flatten_csg1024_is_one_running_min():
             ends.append(end)
 
 
+def test_flatten_culls_a_carved_out_union():
+    """komunajo(A, komplemento(union of 3+)): the union sits behind a bounding-sphere test on -A
+    (it is at most r - |p - c|, so far from it the running max cannot rise)."""
+    st, listing = api.flatten_scene(kat_scenes.tables()["carved"])
+    ops = [line.split()[1] for line in listing.strip().splitlines()]
+    assert ops[:3] == ["KUBO", "CULL", "PUSHA_R"] and ops[6:] == ["NEG", "POPC_R", "END"]
+    assert sorted(ops[3:6]) == ["CILINDRO", "SFERO", "SFERO"]          # the union's members, regrouped by position
+    assert "CULL         src=F dst=P neg" in listing
+
+
 def test_flatten_stack_discipline():
     """Every push has its pop, slots never overlap, frames restore before siblings."""
     for name, table in kat_scenes.tables().items():
