@@ -137,7 +137,10 @@ hipError_t reset_schedule(rm_ctx* c) {
 unsigned render_blocks(const rm_ctx* c, bool jit) {
     const size_t tiles = ((c->width + 7) / 8) * ((c->local_rows + 7) / 8);
     const size_t want = (tiles + 3) / 4;                     // four wavefronts per workgroup, a tile each
-    const size_t resident = static_cast<size_t>(c->cus) * static_cast<size_t>(jit ? c->jit.blocks_per_cu : c->blocks_per_cu);
+    size_t per_cu = static_cast<size_t>(jit ? c->jit.blocks_per_cu : c->blocks_per_cu);
+    if (const char* env = std::getenv("RM_BLOCKS_PER_CU"))   // experiments only
+        if (std::atoi(env) > 0) per_cu = static_cast<size_t>(std::atoi(env));
+    const size_t resident = static_cast<size_t>(c->cus) * per_cu;
     return static_cast<unsigned>(want < resident ? want : resident);
 }
 

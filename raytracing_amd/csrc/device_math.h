@@ -126,9 +126,25 @@ __device__ __forceinline__ P3 rotq(P3 p, float xx, float xy, float xz, float yx,
               p.y + 2.f * (yx * p.x + yy * p.y + yz * p.z),
               p.z + 2.f * (zx * p.x + zy * p.y + zz * p.z)};
 }
+// ripeto_t: generated code names the components of `a` that are zero.  Such a one adds +-0 to the dot product and takes
+// N * 0 = +-0 off its coordinate (positions and N are finite): without its terms a result can
+// differ only in the sign of a zero, which nothing downstream tells apart (no division by, square
+// root of or copysign from such a value; comparisons and sums of squares do not see it).
+template <bool ZX, bool ZY, bool ZZ>
+__device__ __forceinline__ P3 ripeto_t(P3 p, float ax, float ay, float az, float aa, float raa) {
+    float dot;
+    if (ZX && ZY) dot = az * p.z;
+    else if (ZX && ZZ) dot = ay * p.y;
+    else if (ZY && ZZ) dot = ax * p.x;
+    else if (ZX) dot = ay * p.y + az * p.z;
+    else if (ZY) dot = ax * p.x + az * p.z;
+    else if (ZZ) dot = ax * p.x + ay * p.y;
+    else dot = dot3(ax, ay, az, p.x, p.y, p.z);
+    float N = floorf(div_const(dot, aa, raa) + .5f);
+    return P3{ZX ? p.x : p.x - N * ax, ZY ? p.y : p.y - N * ay, ZZ ? p.z : p.z - N * az};
+}
 __device__ __forceinline__ P3 ripeto(P3 p, float ax, float ay, float az, float aa, float raa) {
-    float N = floorf(div_const(dot3(ax, ay, az, p.x, p.y, p.z), aa, raa) + .5f);
-    return P3{p.x - N * ax, p.y - N * ay, p.z - N * az};
+    return ripeto_t<false, false, false>(p, ax, ay, az, aa, raa);
 }
 
 // ---- leaf normals (Source/cuda_kernels.cu:94-104, :120-126), unnormalised ----

@@ -32,6 +32,13 @@ std::string lit3(const float* f) { return lit(f[0]) + ", " + lit(f[1]) + ", " + 
 
 std::string fn(char kind, size_t idx) { return std::string(1, kind) + std::to_string(idx); }
 
+// ripeto(point, a, dot(a,a), its reciprocal), the zero components of `a` named (device_math.h, ripeto_t)
+std::string ripeto_call(const std::string& pv, float ax, float ay, float az, float aa, float raa) {
+    auto z = [](float v) { return v == 0.f ? "true" : "false"; };
+    return std::string("ripeto_t<") + z(ax) + ", " + z(ay) + ", " + z(az) + ">(" + pv + ", " + lit(ax) + ", " + lit(ay) + ", " +
+           lit(az) + ", " + lit(aa) + ", " + lit(raa) + ")";
+}
+
 // Source/cuda_kernels.cu:504-525, same operations in the same order as scene_build.cpp
 void build_q(const rm_node& nd, float Q[9]) {
     const float qw = nd.f[0], qx = nd.f[1], qy = nd.f[2], qz = nd.f[3];
@@ -46,7 +53,10 @@ void build_q(const rm_node& nd, float Q[9]) {
 
 // the two kernels built on a JitScene, whichever generator wrote it
 const char kJitKernels[] = R"(
-extern "C" __global__ void __launch_bounds__(RM_BLOCK_THREADS) rm_render_jit(const rm::RenderParams prm) {
+#ifndef RM_KERNEL_ATTR
+#define RM_KERNEL_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(RM_BLOCK_THREADS) RM_KERNEL_ATTR rm_render_jit(const rm::RenderParams prm) {
     rm::render_body<rm::JitScene>(prm);
 }
 
@@ -127,12 +137,25 @@ struct Fused {
         case RM_TYPE_ROTACIOQ: e = "rotq(" + pv + ", " + qlit(nd) + ")"; break;
         default: {                              // senfina_ripeto
             const float aa = ripeto_aa(nd);
-            e = "ripeto(" + pv + ", " + lit3(nd.f) + ", " + lit(aa) + ", " + lit(divisor_reciprocal(exact, aa)) + ")";
+            e = ripeto_call(pv, nd.f[0], nd.f[1], nd.f[2], aa, divisor_reciprocal(exact, aa));
         }
         }
         dist += "    " + q + " = " + e + ";\n";
         pmemo[key] = q;
         return q;
+    }
+
+    // operands of the min (want_min) or max chain that node i, negated or not, continues
+    void chain(size_t i, const std::string& pv, bool neg, bool want_min, std::vector<std::pair<std::string, bool>>& ops) {
+        const rm_node& nd = nodes[i];
+        const bool comb = nd.type == RM_TYPE_KUNIGAJO_2 || nd.type == RM_TYPE_KUNIGAJO_3 || nd.type == RM_TYPE_KUNIGAJO_4 ||
+                          nd.type == RM_TYPE_KOMUNAJO_2 || nd.type == RM_TYPE_KOMUNAJO_3 || nd.type == RM_TYPE_KOMUNAJO_4;
+        if (nd.type == RM_TYPE_KOMPLEMENTO) { chain(kid(i, 0), pv, !neg, want_min, ops); return; }
+        if (comb && (is_min(nd.type) != neg) == want_min) {
+            for (int c = 0; c < node_arity(nd.type); ++c) chain(kid(i, c), pv, neg, want_min, ops);
+            return;
+        }
+        ops.emplace_back(d(i, pv), neg);
     }
 
     std::string d(size_t i, const std::string& pv) {
@@ -165,17 +188,64 @@ struct Fused {
             break;
         }
         default: {                              // kunigajo_N / komunajo_N
-            const int na = node_arity(nd.type);
-            const std::string sel = is_min(nd.type) ? "as_f(0xff800000u)" : "as_f(0x7f800000u)";
-            std::vector<std::string> a;
-            for (int c = 0; c < na; ++c) a.push_back(d(kid(i, c), pv));
-            std::string e = a[0];
-            for (int c = 1; c < na; ++c) e = "__builtin_amdgcn_fmed3f(" + e + ", " + a[static_cast<size_t>(c)] + ", " + sel + ")";
-            leaf(e);
+            // The whole chain under this node as one list: nested combinators of the same effective
+            // kind are merged, a komplemento flips min and max below it and negates the operands
+            // (-min(a, b) = max(-a, -b)).  Emitted as v_min3 / v_max3 with the negations in the
+            // instruction, written out: through the compiler each operand it cannot prove canonical
+            // would cost an extra v_max x, x.
+            std::vector<std::pair<std::string, bool>> ops;
+            const bool mn = is_min(nd.type);
+            chain(i, pv, false, mn, ops);
+            const char* op3 = mn ? "v_min3_f32" : "v_max3_f32";
+            const char* op2 = mn ? "v_min_f32_e64" : "v_max_f32_e64";
+            auto src = [&](size_t k, int arg) { return std::string(ops[k].second ? "-%" : "%") + std::to_string(arg); };
+            v = new_f();
+            size_t at = 0;
+            std::string acc;                    // variable holding the running value, never negated
+            while (at < ops.size()) {
+                const size_t left = ops.size() - at;
+                std::string text, ins;
+                if (acc.empty() && left >= 3) {
+                    text = std::string(op3) + " %0, " + src(at, 1) + ", " + src(at + 1, 2) + ", " + src(at + 2, 3);
+                    ins = "\"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + "), \"v\"(" + ops[at + 2].first + ")";
+                    at += 3;
+                } else if (acc.empty()) {       // exactly two operands in all
+                    text = std::string(op2) + " %0, " + src(at, 1) + ", " + src(at + 1, 2);
+                    ins = "\"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + ")";
+                    at += 2;
+                } else if (left >= 2) {
+                    text = std::string(op3) + " %0, %1, " + src(at, 2) + ", " + src(at + 1, 3);
+                    ins = "\"v\"(" + acc + "), \"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + ")";
+                    at += 2;
+                } else {
+                    text = std::string(op2) + " %0, %1, " + src(at, 2);
+                    ins = "\"v\"(" + acc + "), \"v\"(" + ops[at].first + ")";
+                    at += 1;
+                }
+                dist += "    asm(\"" + text + "\" : \"=v\"(" + v + ") : " + ins + ");\n";
+                acc = v;
+            }
         }
         }
         dmemo[key] = v;
         return v;
+    }
+
+    // DIST(node i, pv) for the normal's selections: the variable of the distance pass where it made
+    // one, else (a combinator or komplemento the pass merged into its parent's chain) an expression
+    // over its children, evaluated only by the lanes that take a normal
+    std::string value(size_t i, const std::string& pv) {
+        auto it = dmemo.find(std::make_pair(i, pv));
+        if (it != dmemo.end()) return it->second;
+        const rm_node& nd = nodes[i];
+        if (nd.type == RM_TYPE_KOMPLEMENTO) return "(-" + value(kid(i, 0), pv) + ")";
+        const int na = node_arity(nd.type);
+        const bool comb = nd.type == RM_TYPE_KUNIGAJO_2 || nd.type == RM_TYPE_KUNIGAJO_3 || nd.type == RM_TYPE_KUNIGAJO_4 ||
+                          nd.type == RM_TYPE_KOMUNAJO_2 || nd.type == RM_TYPE_KOMUNAJO_3 || nd.type == RM_TYPE_KOMUNAJO_4;
+        if (!comb) return d(i, pv);
+        std::string e = value(kid(i, 0), pv);
+        for (int c = 1; c < na; ++c) e = std::string(is_min(nd.type) ? "min2(" : "max2(") + e + ", " + value(kid(i, c), pv) + ")";
+        return e;
     }
 
     // statements that leave NORM(node i, pv) in `out`
@@ -208,7 +278,7 @@ struct Fused {
             norm += pad + out + " = rotq_back(" + out + ", " + qlit(nd) + ");\n";
             break;
         case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: {
-            const std::string a = d(kid(i, 0), pv), b = d(kid(i, 1), pv), id = std::to_string(counter++);
+            const std::string a = value(kid(i, 0), pv), b = value(kid(i, 1), pv), id = std::to_string(counter++);
             const std::string h = "h" + id, na = "na" + id, nb = "nb" + id;
             norm += pad + "const float " + h + " = glata_h(" + a + ", " + b + ", " + lit(nd.f[0]) + ", " +
                     lit(divisor_reciprocal(exact, nd.f[0])) + ", " + (nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? "true" : "false") + ");\n";
@@ -226,7 +296,7 @@ struct Fused {
             const int na = node_arity(nd.type);
             const bool mn = is_min(nd.type);
             std::vector<std::string> a;
-            for (int c = 0; c < na; ++c) a.push_back(d(kid(i, c), pv));
+            for (int c = 0; c < na; ++c) a.push_back(value(kid(i, c), pv));
             if (na == 2) {                      // ties go to child 1 (:153, :252)
                 norm += pad + "if (" + a[0] + (mn ? " < " : " > ") + a[1] + ") {\n";
                 n(kid(i, 0), pv, out, depth + 1);
@@ -308,7 +378,7 @@ std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned
             break;
         case RM_TYPE_SENFINA_RIPETO: {
             const float aa = ripeto_aa(nd);
-            const std::string t = "ripeto(p, " + lit3(nd.f) + ", " + lit(aa) + ", " + lit(divisor_reciprocal(exact, aa)) + ")";
+            const std::string t = ripeto_call("p", nd.f[0], nd.f[1], nd.f[2], aa, divisor_reciprocal(exact, aa));
             s += d + "return " + fn('d', kid(0)) + "(" + t + "); }\n";
             s += nn + "return " + fn('n', kid(0)) + "(" + t + "); }\n";
             break;
@@ -452,7 +522,12 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
         case OP_ROTQ_Z:
             s += pad + "P = P3{tx, ty, " + S + ".z + 2.f * (" + f1 + " * " + S + ".x + " + f2 + " * " + S + ".y + " + f3 + " * " + S + ".z)};" + to_f + "\n";
             break;
-        case OP_RIPETO:  s += pad + "P = ripeto(" + S + ", " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ", " + f5 + ");" + to_f + "\n"; break;
+        case OP_RIPETO: {
+            float a[5];
+            std::memcpy(a, &sl.w[1], sizeof a);
+            s += pad + "P = " + ripeto_call(S, a[0], a[1], a[2], a[3], a[4]) + ";" + to_f + "\n";
+            break;
+        }
         case OP_SETF:    s += pad + "F = P;\n"; break;
         case OP_SFERO:   prim("sfero_dist(" + moved + ", " + f4 + ")"); break;
         case OP_KUBO:    prim("kubo_dist(" + moved + ", " + f4 + ", " + f5 + ", " + f6 + ")"); break;
@@ -691,9 +766,29 @@ hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_b
             std::fclose(f);
         }
     }
+    JitKernels k;
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return e;
     if (code.empty()) {
         (void)jit_build_code(arch, source, &code, log);
         if (code.empty()) return hipErrorInvalidSource;
+        // A kernel whose vector registers allow eight wavefronts per SIMD is held to six by its
+        // scalar registers (measured on MI355X: 106 SGPRs -> 6 resident, <= 96 -> 7, <= 80 -> 8,
+        // whatever the occupancy query says).  Such a kernel is built again with the compiler told
+        // to fit eight; the spilled scalars cost less than the two wavefronts bring (infinity.sce
+        // 4K 1.105 -> 1.056 ms).  Larger kernels gain nothing from it (chair.sce: 65 VGPRs).
+        if (load_module(code, lds_bytes, &k) == hipSuccess && k.vgprs > 0 && k.vgprs <= 64 && k.scratch == 0 &&
+            !(flags && std::strstr(flags, "RM_KERNEL_ATTR"))) {
+            std::vector<char> tight;
+            JitKernels k2;
+            std::string log2;
+            if (jit_build_code(arch, "#define RM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))\n" + source, &tight, &log2) &&
+                load_module(tight, lds_bytes, &k2) == hipSuccess && k2.vgprs <= 64 && k2.scratch == 0)
+                code.swap(tight);
+            if (k2.module) (void)hipModuleUnload(k2.module);
+        }
+        if (k.module) (void)hipModuleUnload(k.module);
+        k = JitKernels();
         if (!path.empty()) {
             if (std::FILE* f = std::fopen((path + ".tmp").c_str(), "wb")) {
                 const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
@@ -701,9 +796,7 @@ hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_b
             }
         }
     }
-    JitKernels k;
-    e = hipSetDevice(device);
-    if (e == hipSuccess) e = load_module(code, lds_bytes, &k);
+    e = load_module(code, lds_bytes, &k);
     if (e != hipSuccess) { if (k.module) (void)hipModuleUnload(k.module); return e; }
     g_cache[CacheKey{device, hash}] = k;
     *out = k;
