@@ -70,7 +70,8 @@ def measured_traffic(workload):
     """HBM bytes per launch from the last committed counter profile of this workload (rocprofv3 --pmc
     cannot run inside the timed region): {"bytes": ..., "source": ...} or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v4_counters.json")) as f:
+        import glob
+        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))[-1]) as f:      # the latest build profiled
             rec = json.load(f)
         if rec.get("workload") == workload:
             return {"bytes": rec["hbm_bytes_per_launch"], "source": rec["source"]}
