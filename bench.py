@@ -111,9 +111,16 @@ def main():
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for N>1 (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--norm-batch", type=int, default=0)
-    ap.add_argument("--in-flight", type=int, default=0, help="contexts taking frames in turn (0 = 1 for N=1, 3 for N>1)")
+    ap.add_argument("--in-flight", type=int, default=0, help="contexts taking frames in turn (0 = 1 for N=1, 4 for N>1)")
+    ap.add_argument("--gather-batch", type=int, default=4, help="N>1: frames a context renders between two gathers")
     args = ap.parse_args()
 
+    # N>1: four contexts render a rank's shares of consecutive frames at once, each on its own stream,
+    # beside the gather's two streams.  HIP maps streams onto 4 hardware queues by default and streams
+    # that share one run in turn (measured, tools/slice_rate.py: 4 in flight 9.9 k band-sets/s on 4
+    # queues, 16.7 k on 8), so ask for 8 before the runtime starts.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from raytracing_amd import api, tiling
@@ -149,7 +156,7 @@ def main():
     if args.workload.endswith("_sweep"):
         sweep = np.fromfile(os.path.join(ROOT, "tests", "golden", "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
     want = None if sweep is not None else golden_frame(scene, w, h)
-    in_flight = args.in_flight or (1 if world == 1 else 3)
+    in_flight = args.in_flight or (1 if world == 1 else 4)
 
     # one context per frame in flight, each on a stream of its own
     ctxs, streams = [], []
@@ -165,21 +172,24 @@ def main():
         streams.append(st)
 
     band = 0
+    batch = max(1, args.gather_batch)
     if world > 1:
+        # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
+        # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), `batch` frames of a
+        # context per RCCL gather, and rank 0 rebuilds each RGBA8 frame from the planes of all ranks
+        # (rm_assemble_luminance).  At 4 B/px and 8 ranks the gather alone (29 MB per frame into one
+        # GPU's xGMI links) would bound the frame rate below what the kernels deliver.
         band = args.band_rows or tiling.default_band_rows(h, world)
         rows_max = tiling.bands_per_rank(h, band, world) * band
         comm_stream = torch.cuda.Stream(device=dev)
         bufs, parts, rendered, gathered = [], [], [], []
         for rm in ctxs:
             rm.set_bands(band, rank, world)
-            bufs.append(torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev))
-            rm.set_output(bufs[-1].data_ptr(), w * 4)
-            parts.append(torch.zeros((world, rows_max, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None)
+            bufs.append(torch.zeros((batch, rows_max, w), dtype=torch.uint8, device=dev))
+            parts.append(torch.zeros((world, batch, rows_max, w), dtype=torch.uint8, device=dev) if rank == 0 else None)
             rendered.append(torch.cuda.Event())
             gathered.append(torch.cuda.Event())
-        frame_padded = (torch.zeros((tiling.padded_rows(h, band, world), w, 4), dtype=torch.uint8, device=dev)
-                        if rank == 0 else None)
-        frame = frame_padded[:h] if rank == 0 else None
+        frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
         frames = [frame]
     else:
         frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in ctxs]
@@ -187,15 +197,13 @@ def main():
             rm.set_output(f.data_ptr(), w * 4)
         frame = frames[0]
 
-    def step(k):
-        j = k % in_flight
-        rm = ctxs[j]
-        rm.set_info(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
-        if world == 1:
-            rm.process_async()
+    state = {"ctx": 0, "slot": 0}           # N>1: the context taking frames and how many its slab holds
+
+    def flush():
+        """Gather the current context's slab to rank 0, rebuild its frames there, move on to the next context."""
+        j, filled = state["ctx"], state["slot"]
+        if filled == 0:
             return
-        streams[j].wait_event(gathered[j])             # context j's band buffer is free again
-        rm.process_async()
         rendered[j].record(streams[j])
         comm_stream.wait_event(rendered[j])
         with torch.cuda.stream(comm_stream):           # same order of gathers on every rank
@@ -209,10 +217,32 @@ def main():
             else:
                 dist.gather(bufs[j], list(parts[j].unbind(0)) if rank == 0 else None, dst=0)
             if rank == 0:
-                tiling.assemble_into(frame_padded, parts[j], band)
+                for slot in range(filled):
+                    ctxs[j].assemble_luminance(parts[j].data_ptr() + slot * rows_max * w, batch * rows_max * w, w,
+                                               frame.data_ptr(), w * 4, stream=comm_stream.cuda_stream)
             gathered[j].record(comm_stream)
+        state["ctx"], state["slot"] = (j + 1) % in_flight, 0
+
+    def step(k):
+        if world == 1:
+            rm = ctxs[k % in_flight]
+            rm.set_info(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
+            rm.process_async()
+            return
+        j, slot = state["ctx"], state["slot"]
+        rm = ctxs[j]
+        if slot == 0:
+            streams[j].wait_event(gathered[j])         # context j's slab is free again
+        rm.set_info(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
+        rm.set_luminance_output(bufs[j][slot].data_ptr(), w)
+        rm.process_async()
+        state["slot"] = slot + 1
+        if slot + 1 == batch:
+            flush()
 
     def drain():
+        if world > 1:
+            flush()                                    # a slab that is not full yet
         for st in streams:
             st.synchronize()
         if world > 1:
@@ -263,7 +293,8 @@ def main():
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
                        "scene_nodes": int(len(nodes)), "frames_in_flight": in_flight,
                        "partition": "whole frame" if world == 1 else
-                       "row bands of %d dealt round-robin over %d ranks, RCCL gather to rank 0" % (band, world)},
+                       "row bands of %d dealt round-robin over %d ranks; RCCL gather of the luminance planes (1 B/px) to "
+                       "rank 0 every %d frames, RGBA8 frames rebuilt there" % (band, world, batch)},
             "parity": {"hit_pixels": hits, "rgba_sha256": sha,
                        "golden_hit_pixels": want["hits"] if want else None,
                        "frame_matches_golden": (sha == want["rgba_sha256"]) if want else None},

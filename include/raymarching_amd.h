@@ -102,6 +102,24 @@ int rm_set_info(rm_ctx* ctx, const rm_rays_info* info);
 int rm_set_bands(rm_ctx* ctx, size_t band_rows, int rank, int nranks);
 int rm_local_rows(rm_ctx* ctx, size_t* rows);
 
+/* Optional luminance plane (no counterpart in the reference): besides the RGBA8
+ * frame the kernel writes, into a caller-owned DEVICE buffer, one byte per pixel:
+ * the 8-bit luminance L of Source/cuda_kernels.cu:694, 0 where nothing was hit.
+ * A pixel is a function of L alone (:695-699 scale it by the material constants;
+ * a miss is the black of L = 0), so a multi-GPU gather can move this plane, a
+ * quarter of the bytes, and rebuild the identical RGBA8 frame on the receiving
+ * device.  Rows follow the context's band layout like the RGBA8 output.  NULL
+ * switches the plane off. */
+int rm_set_luminance_output(rm_ctx* ctx, void* device_l8, size_t pitch_bytes);
+
+/* Rebuilds the whole RGBA8 frame from the luminance planes of all ranks: part r
+ * (rank r's plane, rows packed as rm_set_bands lays them out, `part_pitch_bytes`
+ * apart) starts at device_parts + r * rank_stride_bytes.  Uses this context's
+ * image size and band layout (band_rows = 0: one part, a plain expansion).
+ * Runs on `hip_stream` (a hipStream_t; NULL = the null stream), asynchronously. */
+int rm_assemble_luminance(rm_ctx* ctx, const void* device_parts, size_t rank_stride_bytes, size_t part_pitch_bytes,
+                          void* device_rgba, size_t pitch_bytes, void* hip_stream);
+
 /* Optional explicit hit mask: one byte per
  * pixel, 1 where the pixel was shaded.  enable != 0 allocates it. */
 int rm_enable_hit_mask(rm_ctx* ctx, int enable);

@@ -29,6 +29,7 @@ EXPORTS = [
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
+    "rm_set_luminance_output", "rm_assemble_luminance",
 ]
 
 
@@ -75,6 +76,8 @@ def lib():
             "rm_destroy": [vp],
             "rm_set_stream": [vp, vp],
             "rm_set_output": [vp, vp, sz],
+            "rm_set_luminance_output": [vp, vp, sz],
+            "rm_assemble_luminance": [vp, vp, sz, sz, vp, sz, vp],
             "rm_set_primitives": [vp, vp, sz, i32],
             "rm_set_nodes": [vp, vp, sz],
             "rm_set_info": [vp, vp],
@@ -209,6 +212,15 @@ class Raymarching:
 
     def set_output(self, device_ptr, pitch_bytes):
         _check(lib().rm_set_output(self._ctx, C.c_void_p(device_ptr), pitch_bytes), "rm_set_output")
+
+    def set_luminance_output(self, device_ptr, pitch_bytes):
+        """One byte per pixel besides the RGBA8 frame (a quarter of the bytes to gather); 0/None switches it off."""
+        _check(lib().rm_set_luminance_output(self._ctx, C.c_void_p(device_ptr or None), pitch_bytes), "rm_set_luminance_output")
+
+    def assemble_luminance(self, parts_ptr, rank_stride, part_pitch, rgba_ptr, pitch_bytes, stream=None):
+        """RGBA8 frame from every rank's luminance plane (this context's image size and band layout)."""
+        _check(lib().rm_assemble_luminance(self._ctx, C.c_void_p(parts_ptr), rank_stride, part_pitch, C.c_void_p(rgba_ptr),
+                                           pitch_bytes, C.c_void_p(stream or None)), "rm_assemble_luminance")
 
     def set_bands(self, band_rows, rank, nranks):
         _check(lib().rm_set_bands(self._ctx, band_rows, rank, nranks), "rm_set_bands")

@@ -30,6 +30,8 @@ struct rm_ctx {
     uint8_t* out = nullptr;           // where rm_process writes (fb or caller's buffer)
     size_t out_pitch = 0;
     uint8_t* hit = nullptr;           // optional hit mask, width pitch
+    uint8_t* lum = nullptr;           // optional caller-owned luminance plane
+    size_t lum_pitch = 0;
 
     rm::SceneBuild scene;
     rm::Slot* d_program = nullptr;
@@ -108,6 +110,7 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     p.evaluator = c->evaluator;
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;
+    p.lum = c->lum;  p.lum_pitch = c->lum_pitch;
     p.cam = c->cam;
     p.boost_age = c->boost_age;
     const uint32_t cur = c->seq % 3, prev = (c->seq + 2) % 3, next = (c->seq + 1) % 3;
@@ -136,7 +139,14 @@ hipError_t reset_schedule(rm_ctx* c) {
 // persistent grid: what the chip holds at once, or fewer when the image has few tiles
 unsigned render_blocks(const rm_ctx* c, bool jit) {
     const size_t tiles = ((c->width + 7) / 8) * ((c->local_rows + 7) / 8);
-    const size_t want = (tiles + 3) / 4;                     // four wavefronts per workgroup, a tile each
+    // Four wavefronts per workgroup, and enough tiles per wavefront that starting it and having it
+    // find every queue head dry at the end is small beside its work: a share of a frame (row bands
+    // on 8 ranks) must not launch a wavefront per two tiles, and a smaller grid leaves room for the
+    // kernels of other frames in flight.
+    size_t tiles_per_wave = 8;
+    if (const char* env = std::getenv("RM_TILES_PER_WAVE"))  // experiments only
+        if (std::atoi(env) > 0) tiles_per_wave = static_cast<size_t>(std::atoi(env));
+    const size_t want = (tiles + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
     size_t per_cu = static_cast<size_t>(jit ? c->jit.blocks_per_cu : c->blocks_per_cu);
     if (const char* env = std::getenv("RM_BLOCKS_PER_CU"))   // experiments only
         if (std::atoi(env) > 0) per_cu = static_cast<size_t>(std::atoi(env));
@@ -359,6 +369,32 @@ int rm_set_output(rm_ctx* c, void* device_rgba, size_t pitch_bytes) {
     if (pitch_bytes < c->width * 4 || (pitch_bytes & 3) || (reinterpret_cast<uintptr_t>(device_rgba) & 3))
         return RM_ERR_INVALID_ARG;
     c->out = static_cast<uint8_t*>(device_rgba); c->out_pitch = pitch_bytes;
+    return RM_OK;
+}
+
+int rm_set_luminance_output(rm_ctx* c, void* device_l8, size_t pitch_bytes) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    if (!device_l8) { c->lum = nullptr; c->lum_pitch = 0; return RM_OK; }
+    if (pitch_bytes < c->width) return RM_ERR_INVALID_ARG;
+    c->lum = static_cast<uint8_t*>(device_l8); c->lum_pitch = pitch_bytes;
+    return RM_OK;
+}
+
+int rm_assemble_luminance(rm_ctx* c, const void* device_parts, size_t rank_stride_bytes, size_t part_pitch_bytes,
+                          void* device_rgba, size_t pitch_bytes, void* hip_stream) {
+    if (!c || !device_parts || !device_rgba) return RM_ERR_INVALID_ARG;
+    if (part_pitch_bytes < c->width || pitch_bytes < c->width * 4 || (pitch_bytes & 3) ||
+        (reinterpret_cast<uintptr_t>(device_rgba) & 3))
+        return RM_ERR_INVALID_ARG;
+    // every rank's part must hold that rank's rows: the largest share is rank 0's
+    const size_t nranks = c->band_rows ? static_cast<size_t>(c->nranks) : 1;
+    const size_t rows_max = c->band_rows ? count_local_rows(c->height, c->band_rows, 0, c->nranks) : c->height;
+    if (nranks > 1 && rank_stride_bytes < rows_max * part_pitch_bytes) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(rm::launch_assemble_luminance(static_cast<const uint8_t*>(device_parts), rank_stride_bytes, part_pitch_bytes,
+                                          static_cast<uint32_t>(c->width), static_cast<uint32_t>(c->height),
+                                          static_cast<uint32_t>(c->band_rows), static_cast<uint32_t>(nranks),
+                                          static_cast<uint8_t*>(device_rgba), pitch_bytes, static_cast<hipStream_t>(hip_stream)));
     return RM_OK;
 }
 

@@ -95,7 +95,12 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             for (int b = 0; b < RM_COST_BUCKETS; ++b) a_cum[b] = 0;
             a_total = (a_head < RM_QUEUE_HEADS && ntiles > a_head) ? (ntiles - a_head + RM_QUEUE_HEADS - 1) / RM_QUEUE_HEADS : 0;
         }
-        a_ticket = bump(RM_SET_PULL(a_head));
+        // A head that is already dry costs a load, not an atomic: at the end of a frame every wave
+        // walks all the heads, and atomics on one word go through L2 one at a time (~88 per us).
+        // The counter only grows, so a stale value can only send a wave to the atomic needlessly.
+        const uint32_t seen = uniform(__hip_atomic_load(prm.set_cur + RM_SET_PULL(a_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (seen >= a_total) a_ticket = a_total;
+        else a_ticket = bump(RM_SET_PULL(a_head));
     };
     // stage S: a tile id on its way (list entry), or already known (natural order)
     uint32_t s_val = 0;
@@ -261,6 +266,9 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         if (in_image) {                                                            // :717
             *reinterpret_cast<uint32_t*>(prm.rgba + (size_t)ly * prm.pitch + (size_t)px * 4) = pixel;
             if (prm.hit) prm.hit[(size_t)ly * prm.hit_pitch + (size_t)px] = (uint8_t)hit;
+            // the luminance byte L of :694 is the blue channel (RM_MATERIAL_B is 1): a pixel is a function of L alone
+            static_assert(RM_MATERIAL_B == 1.f, "the luminance plane reads L back from the blue channel");
+            if (prm.lum) prm.lum[(size_t)ly * prm.lum_pitch + (size_t)px] = (uint8_t)(pixel >> 16);
         }
 
         // ---- file the tile under its cost for the next frame

@@ -47,6 +47,7 @@ struct RenderParams {
     uint32_t evaluator;           // 0 distance program, 1 tree walker
     uint8_t* rgba;  size_t pitch;
     uint8_t* hit;   size_t hit_pitch;
+    uint8_t* lum;   size_t lum_pitch;   // optional luminance plane, 1 B/px (rm_set_luminance_output)
     uint32_t* wave_stats;         // optional diagnostics, 4 dwords per wavefront
     // tile scheduler (device_render.h): this frame owns set_cur (all zero when it starts), reads the
     // lists the previous frame wrote (counts in set_prev), and zeroes set_next for the frame after it
@@ -73,6 +74,9 @@ hipError_t launch_eval_rays(const RenderParams& prm, const int* xy, uint32_t cou
 hipError_t configure_lds(size_t lds_bytes);
 hipError_t kernel_attributes(int* vgprs, int* scratch_bytes);
 // enumeration proofs of device_math.h's short sqrt / quotient sequences (mismatch counts in *bad)
+// luminance planes of `nranks` band-interleaved parts -> one RGBA8 frame (rm_assemble_luminance)
+hipError_t launch_assemble_luminance(const uint8_t* parts, size_t rank_stride, size_t part_pitch, uint32_t width, uint32_t height,
+                                     uint32_t band_rows, uint32_t nranks, uint8_t* rgba, size_t pitch, hipStream_t stream);
 hipError_t launch_verify_sqrt(uint32_t first, unsigned long long count, unsigned long long* bad, hipStream_t stream);
 hipError_t launch_verify_div(const float* c, const float* rc, uint32_t n, uint32_t first, unsigned long long count,
                              unsigned long long* bad, hipStream_t stream);

@@ -100,6 +100,39 @@ verify_div_kernel(const float* __restrict__ c, const float* __restrict__ rc, uin
 
 // ---- launchers (called from capi.cpp) -----------------------------------------
 
+// One thread per 4 pixels of the assembled frame: finds the rank and packed row that hold the
+// pixels' band, reads 4 luminance bytes, writes 16 bytes of RGBA8 built as :694-699 build them.
+__global__ void __launch_bounds__(256)
+assemble_luminance_kernel(const uint8_t* __restrict__ parts, size_t rank_stride, size_t part_pitch, uint32_t width, uint32_t height,
+                          uint32_t band_rows, uint32_t nranks, uint8_t* __restrict__ rgba, size_t pitch) {
+    const uint32_t quads = (width + 3) / 4;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint64_t)quads * height) return;
+    const uint32_t y = (uint32_t)(i / quads), x0 = (uint32_t)(i % quads) * 4;
+    uint32_t r = 0, ly = y;
+    if (band_rows) {
+        const uint32_t band = y / band_rows;
+        r = band % nranks;
+        ly = (band / nranks) * band_rows + y % band_rows;
+    }
+    const uint8_t* src = parts + (size_t)r * rank_stride + (size_t)ly * part_pitch + x0;
+    uint8_t* dst = rgba + (size_t)y * pitch + (size_t)x0 * 4;
+    for (uint32_t k = 0; k < 4 && x0 + k < width; ++k) {
+        const float L = (float)src[k];
+        reinterpret_cast<uint32_t*>(dst)[k] =
+            to_u8(L * RM_MATERIAL_R) | (to_u8(L * RM_MATERIAL_G) << 8) | (to_u8(L * RM_MATERIAL_B) << 16) | 0xff000000u;
+    }
+}
+
+hipError_t launch_assemble_luminance(const uint8_t* parts, size_t rank_stride, size_t part_pitch, uint32_t width, uint32_t height,
+                                     uint32_t band_rows, uint32_t nranks, uint8_t* rgba, size_t pitch, hipStream_t stream) {
+    const uint64_t threads = (uint64_t)((width + 3) / 4) * height;
+    if (!threads) return hipSuccess;
+    hipLaunchKernelGGL(assemble_luminance_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                       parts, rank_stride, part_pitch, width, height, band_rows, nranks, rgba, pitch);
+    return hipGetLastError();
+}
+
 hipError_t launch_verify_sqrt(uint32_t first, unsigned long long count, unsigned long long* bad, hipStream_t stream) {
     hipLaunchKernelGGL(verify_sqrt_kernel, dim3(2048), dim3(256), 0, stream, first, count, bad);
     return hipGetLastError();

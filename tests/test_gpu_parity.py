@@ -208,6 +208,40 @@ def test_row_bands_reassemble(stock_scenes):
         assert np.array_equal(frame, whole)
 
 
+@pytest.mark.parametrize("name", ["chair", "infinity"])
+def test_luminance_planes_rebuild_the_frame(stock_scenes, name):
+    """rm_set_luminance_output + rm_assemble_luminance: one byte per pixel from every rank, put back
+    together on one device, is the RGBA8 frame byte for byte (whole frame and 3-rank bands, odd width)."""
+    torch = pytest.importorskip("torch")
+    info = O.default_info(1, 0)
+    w, h = 322, 250
+    whole, _, _ = gpu_render(stock_scenes[name], w, h, info)
+    for nranks, band in [(1, 0), (3, 32), (8, 16)]:
+        rows_max = -(-h // (band * nranks)) * band if band else h
+        pitch = w + 5
+        parts = torch.full((nranks, rows_max, pitch), 0xAB, dtype=torch.uint8, device="cuda")
+        keep = []
+        for rank in range(nranks):
+            rm = api.Raymarching(w, h)
+            rm.set_nodes(stock_scenes[name])
+            rm.set_info(info)
+            if band:
+                rm.set_bands(band, rank, nranks)
+            rm.set_luminance_output(parts[rank].data_ptr(), pitch)
+            rm.process()
+            # the RGBA8 output is still written, and is this rank's share of the frame
+            assert np.array_equal(rm.read_pixels()[:, :, 2], parts[rank, :rm.local_rows(), :w].cpu().numpy())
+            keep.append(rm)
+        out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        keep[0].assemble_luminance(parts.data_ptr(), rows_max * pitch, pitch, out.data_ptr(), w * 4)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), whole), (nranks, band)
+        with pytest.raises(api.RaymarchError):
+            keep[0].assemble_luminance(parts.data_ptr(), rows_max * pitch, w - 1, out.data_ptr(), w * 4)
+        for rm in keep:
+            rm.close()
+
+
 def test_external_output_and_pitch(stock_scenes):
     """rm_set_output: render into a caller-owned device buffer with a padded pitch."""
     torch = pytest.importorskip("torch")
