@@ -111,8 +111,9 @@ def main():
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for N>1 (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--norm-batch", type=int, default=0)
-    ap.add_argument("--in-flight", type=int, default=0, help="contexts taking frames in turn (0 = 1 for N=1, 4 for N>1)")
-    ap.add_argument("--gather-batch", type=int, default=4, help="N>1: frames a context renders between two gathers")
+    ap.add_argument("--in-flight", type=int, default=0, help="contexts taking launches in turn (0 = 1 for N=1, 3 for N>1)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="frames whose tiles one launch pools (rm_set_batch), 1..8; 0 = 8")
     args = ap.parse_args()
 
     # N>1: four contexts render a rank's shares of consecutive frames at once, each on its own stream,
@@ -156,7 +157,7 @@ def main():
     if args.workload.endswith("_sweep"):
         sweep = np.fromfile(os.path.join(ROOT, "tests", "golden", "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
     want = None if sweep is not None else golden_frame(scene, w, h)
-    in_flight = args.in_flight or (1 if world == 1 else 4)
+    in_flight = args.in_flight or (1 if world == 1 else 3)
 
     # one context per frame in flight, each on a stream of its own
     ctxs, streams = [], []
@@ -172,11 +173,19 @@ def main():
         streams.append(st)
 
     band = 0
-    batch = max(1, args.gather_batch)
+    # Frames per launch (rm_set_batch): 8 at every N.  The reference renders a frame per Process()
+    # call; here the tiles of 8 consecutive frames of the sequence form one pool for the persistent
+    # wavefronts, so the few long tiles of a frame (one ray marching ~900 steps is 0.2 ms however idle
+    # the chip is) run beside the short tiles of the others.  At N>1 it is what makes a rank's launch
+    # worth launching: an 8-rank share of ONE frame is too little work to fill the chip for as long as
+    # its longest ray marches (tools/slice_rate.py: 5.2 k shares/s per GPU one at a time, 18-22 k/s
+    # with 8 per launch).  `single_frame_launch` in the output is the frame-at-a-time figure.
+    batch = args.frames_per_launch or 8
+    batch = max(1, min(8, batch))
     if world > 1:
         # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
-        # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), `batch` frames of a
-        # context per RCCL gather, and rank 0 rebuilds each RGBA8 frame from the planes of all ranks
+        # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), the frames of a launch
+        # in one RCCL gather, and rank 0 rebuilds each RGBA8 frame from the planes of all ranks
         # (rm_assemble_luminance).  At 4 B/px and 8 ranks the gather alone (29 MB per frame into one
         # GPU's xGMI links) would bound the frame rate below what the kernels deliver.
         band = args.band_rows or tiling.default_band_rows(h, world)
@@ -186,23 +195,40 @@ def main():
         for rm in ctxs:
             rm.set_bands(band, rank, world)
             bufs.append(torch.zeros((batch, rows_max, w), dtype=torch.uint8, device=dev))
+            rm.set_luminance_output(bufs[-1].data_ptr(), w)
             parts.append(torch.zeros((world, batch, rows_max, w), dtype=torch.uint8, device=dev) if rank == 0 else None)
             rendered.append(torch.cuda.Event())
             gathered.append(torch.cuda.Event())
         frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-        frames = [frame]
+        frames = None
+        strides = (0, rows_max * w)                    # RGBA8 into the context's own planes, luminance into the slab
     else:
-        frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in ctxs]
+        frames = [torch.zeros((batch, h, w, 4), dtype=torch.uint8, device=dev) for _ in ctxs]
         for rm, f in zip(ctxs, frames):
             rm.set_output(f.data_ptr(), w * 4)
-        frame = frames[0]
+        frame = None                                   # the last frame rendered: set by launch()
+        strides = (h * w * 4, 0)
+    cur_batch = [1] * in_flight
+    state = {"ctx": 0, "pending": [], "launches": 0, "last": None}
 
-    state = {"ctx": 0, "slot": 0}           # N>1: the context taking frames and how many its slab holds
-
-    def flush():
-        """Gather the current context's slab to rank 0, rebuild its frames there, move on to the next context."""
-        j, filled = state["ctx"], state["slot"]
-        if filled == 0:
+    def launch():
+        """The pending frames as one launch of the current context (then, N>1, their gather to rank 0)."""
+        j, infos = state["ctx"], state["pending"]
+        n = len(infos)
+        if n == 0:
+            return
+        rm = ctxs[j]
+        if world > 1:
+            streams[j].wait_event(gathered[j])         # context j's slab is free again
+        if cur_batch[j] != n:                          # the first launch, and a last one that is not full
+            rm.set_batch(n, *strides)
+            cur_batch[j] = n
+        rm.set_info_batch(np.concatenate(infos))
+        rm.process_async()
+        state["launches"] += 1
+        state["last"] = (j, n - 1)
+        state["ctx"], state["pending"] = (j + 1) % in_flight, []
+        if world == 1:
             return
         rendered[j].record(streams[j])
         comm_stream.wait_event(rendered[j])
@@ -217,39 +243,28 @@ def main():
             else:
                 dist.gather(bufs[j], list(parts[j].unbind(0)) if rank == 0 else None, dst=0)
             if rank == 0:
-                for slot in range(filled):
-                    ctxs[j].assemble_luminance(parts[j].data_ptr() + slot * rows_max * w, batch * rows_max * w, w,
-                                               frame.data_ptr(), w * 4, stream=comm_stream.cuda_stream)
+                for slot in range(n):
+                    rm.assemble_luminance(parts[j].data_ptr() + slot * rows_max * w, batch * rows_max * w, w,
+                                          frame.data_ptr(), w * 4, stream=comm_stream.cuda_stream)
             gathered[j].record(comm_stream)
-        state["ctx"], state["slot"] = (j + 1) % in_flight, 0
 
     def step(k):
-        if world == 1:
-            rm = ctxs[k % in_flight]
-            rm.set_info(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
-            rm.process_async()
-            return
-        j, slot = state["ctx"], state["slot"]
-        rm = ctxs[j]
-        if slot == 0:
-            streams[j].wait_event(gathered[j])         # context j's slab is free again
-        rm.set_info(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
-        rm.set_luminance_output(bufs[j][slot].data_ptr(), w)
-        rm.process_async()
-        state["slot"] = slot + 1
-        if slot + 1 == batch:
-            flush()
+        state["pending"].append(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
+        if len(state["pending"]) == batch:
+            launch()
 
     def drain():
-        if world > 1:
-            flush()                                    # a slab that is not full yet
+        launch()                                       # frames that do not fill a launch
         for st in streams:
             st.synchronize()
         if world > 1:
             comm_stream.synchronize()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
+    # warm-up: whole launches only (a launch that is not full would reset the tile order the
+    # contexts have learnt), so a few frames more than asked when --warmup is no multiple
+    warm = -(-args.warmup // batch) * batch
+    for k in range(warm):
         step(k)
     drain()
     if world > 1:
@@ -257,19 +272,24 @@ def main():
     torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    state["launches"] = 0
     t0 = time.perf_counter()
-    ev0.record(streams[args.warmup % in_flight])
+    ev0.record(streams[state["ctx"]])
     for k in range(args.steps):
-        step(args.warmup + k)
-    ev1.record(streams[(args.warmup + args.steps - 1) % in_flight])
+        step(warm + k)
+    launch()                                           # exactly --steps frames: the last launch may hold fewer
+    ev1.record(streams[state["last"][0]])
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
-    # N = 1, one frame in flight: the kernel's average duration (launch to launch on its stream).
-    # With frames in flight kernels overlap; the per-frame time of the region is what counts then.
-    kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / max(1, args.steps)
+    launches = max(1, state["launches"])
+    # One context: the kernel's average duration (launch to launch on its stream).  With several
+    # in flight kernels overlap; the region's time per launch is what counts then.
+    kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / launches
+    if world == 1:
+        frame = frames[state["last"][0]][state["last"][1]]
 
     if world > 1:
         tmax = torch.tensor([secs], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -291,17 +311,17 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, **({"rehearsal": True} if rehearsal else {}),
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
-                       "scene_nodes": int(len(nodes)), "frames_in_flight": in_flight,
+                       "scene_nodes": int(len(nodes)), "contexts_in_flight": in_flight, "frames_per_launch": batch,
                        "partition": "whole frame" if world == 1 else
-                       "row bands of %d dealt round-robin over %d ranks; RCCL gather of the luminance planes (1 B/px) to "
-                       "rank 0 every %d frames, RGBA8 frames rebuilt there" % (band, world, batch)},
+                       "row bands of %d dealt round-robin over %d ranks; the %d frames of a launch gathered together to rank 0 "
+                       "as luminance planes (1 B/px, RCCL), RGBA8 frames rebuilt there" % (band, world, batch)},
             "parity": {"hit_pixels": hits, "rgba_sha256": sha,
                        "golden_hit_pixels": want["hits"] if want else None,
                        "frame_matches_golden": (sha == want["rgba_sha256"]) if want else None},
-            "kernel_ms": kernel_ms,
+            "kernel_ms": kernel_ms, "launches": launches,
         }
         if want:
-            flops = want["counters"]["flops"] / world      # per launch: each rank renders 1/N of the frame
+            flops = want["counters"]["flops"] / world * args.steps / launches      # per launch: 1/N of each of its frames
             achieved = flops / (kernel_ms * 1e-3) / 1e12
             traffic = measured_traffic(args.workload) if world == 1 else None
             out["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS,
@@ -317,8 +337,18 @@ def main():
                                        "the reference bit for bit, so nothing is contracted into an FMA and sqrt and "
                                        "division are correctly rounded: peak_no_fma is what the chip issues then "
                                        "(measured: tools/microbench/valu_peak.hip)",
-                               "hbm": {"achieved": w * h * 4 / world / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "hbm": {"achieved": w * h * 4 / world * args.steps / launches / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "bytes_per_ray": 4}}
+        if world == 1 and batch > 1:
+            # the same frame one per launch, as the reference's Process() renders it
+            with api.Raymarching(w, h, device=local_rank) as one:
+                one.set_nodes(nodes)
+                one.set_info(info if sweep is None else sweep[0:1])
+                for _ in range(10):
+                    one.process_async()
+                one.synchronize()
+                ms = sorted(one.process() for _ in range(30))[15]
+            out["single_frame_launch"] = {"kernel_ms": ms, "Mrays/s": w * h / ms / 1e3}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, w, h, info, want)
             out["stats"] = ctxs[0].scene_stats()

@@ -94,6 +94,21 @@ int rm_set_nodes(rm_ctx* ctx, const rm_node* nodes, size_t n);
  * is not launched: rm_process derives each pixel's ray from this block. */
 int rm_set_info(rm_ctx* ctx, const rm_rays_info* info);
 
+/* Several frames per launch (no counterpart: the reference renders one frame per
+ * Process()).  After rm_set_batch(ctx, n, ...) every rm_process / rm_process_async
+ * renders n frames (1..RM_MAX_BATCH) in ONE kernel launch: the tiles of all n frames
+ * form one pool for the persistent wavefronts, so the long tiles of one frame run
+ * beside the short ones of the others.  A rank's share of a frame on 8 GPUs is too
+ * little work to fill the chip for as long as its longest ray takes; a batch is.
+ * Frame f uses the f-th camera block of rm_set_info_batch (rm_set_info gives all
+ * frames the same block) and writes its planes `*_frame_stride_bytes` after frame
+ * f-1's: RGBA8 output, luminance plane; 0 = packed (pitch x rows of this context).
+ * With the context's own framebuffer rm_read_pixels returns frame 0.  Changing the
+ * batch forgets the tile order learnt from earlier frames.  Synchronises the stream. */
+#define RM_MAX_BATCH 8
+int rm_set_batch(rm_ctx* ctx, size_t frames, size_t rgba_frame_stride_bytes, size_t luminance_frame_stride_bytes);
+int rm_set_info_batch(rm_ctx* ctx, const rm_rays_info* infos, size_t n);
+
 /* Multi-GPU row bands (no counterpart: the reference is single-device,
  * Source/cuda_rays.cu:20-21).  The image is cut into bands of `band_rows` rows
  * (a multiple of 16); this context renders bands b with b % nranks == rank,

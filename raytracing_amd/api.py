@@ -29,7 +29,7 @@ EXPORTS = [
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
-    "rm_set_luminance_output", "rm_assemble_luminance",
+    "rm_set_luminance_output", "rm_assemble_luminance", "rm_set_batch", "rm_set_info_batch",
 ]
 
 
@@ -77,6 +77,8 @@ def lib():
             "rm_set_stream": [vp, vp],
             "rm_set_output": [vp, vp, sz],
             "rm_set_luminance_output": [vp, vp, sz],
+            "rm_set_batch": [vp, sz, sz, sz],
+            "rm_set_info_batch": [vp, vp, sz],
             "rm_assemble_luminance": [vp, vp, sz, sz, vp, sz, vp],
             "rm_set_primitives": [vp, vp, sz, i32],
             "rm_set_nodes": [vp, vp, sz],
@@ -212,6 +214,15 @@ class Raymarching:
 
     def set_output(self, device_ptr, pitch_bytes):
         _check(lib().rm_set_output(self._ctx, C.c_void_p(device_ptr), pitch_bytes), "rm_set_output")
+
+    def set_batch(self, frames, rgba_frame_stride=0, luminance_frame_stride=0):
+        """`frames` frames per launch, their tiles in one pool (rm_set_batch)."""
+        _check(lib().rm_set_batch(self._ctx, frames, rgba_frame_stride, luminance_frame_stride), "rm_set_batch")
+
+    def set_info_batch(self, infos):
+        """One camera block per frame of the batch (an INFO_DTYPE array)."""
+        infos = np.ascontiguousarray(infos, dtype=INFO_DTYPE)
+        _check(lib().rm_set_info_batch(self._ctx, infos.ctypes.data_as(C.c_void_p), infos.size), "rm_set_info_batch")
 
     def set_luminance_output(self, device_ptr, pitch_bytes):
         """One byte per pixel besides the RGBA8 frame (a quarter of the bytes to gather); 0/None switches it off."""

@@ -38,7 +38,10 @@ struct rm_ctx {
     rm::TreeNode* d_tree = nullptr;
     uint32_t n_nodes = 0;
     bool have_scene = false, have_info = false;
-    rm::Camera cam{};
+    rm::Camera cams[RM_MAX_BATCH];    // cams[f]: camera of frame f of a launch
+    size_t batch = 1;                 // frames per launch (rm_set_batch)
+    size_t out_frame_stride = 0, lum_frame_stride = 0;   // 0: planes packed (pitch x local rows)
+    size_t fb_bytes = 0, hit_bytes = 0;
 
     size_t band_rows = 0; int rank = 0, nranks = 1;
     size_t local_rows = 0;
@@ -111,7 +114,11 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;
     p.lum = c->lum;  p.lum_pitch = c->lum_pitch;
-    p.cam = c->cam;
+    p.nframes = static_cast<uint32_t>(c->batch);
+    p.frame_stride = c->out_frame_stride ? c->out_frame_stride : c->out_pitch * c->local_rows;
+    p.hit_frame_stride = c->width * c->local_rows;
+    p.lum_frame_stride = c->lum_frame_stride ? c->lum_frame_stride : c->lum_pitch * c->local_rows;
+    for (size_t f = 0; f < RM_MAX_BATCH; ++f) p.cams[f] = c->cams[f];
     p.boost_age = c->boost_age;
     const uint32_t cur = c->seq % 3, prev = (c->seq + 2) % 3, next = (c->seq + 1) % 3;
     uint32_t* lists = c->sched + 3 * RM_SET_DWORDS;
@@ -138,7 +145,7 @@ hipError_t reset_schedule(rm_ctx* c) {
 
 // persistent grid: what the chip holds at once, or fewer when the image has few tiles
 unsigned render_blocks(const rm_ctx* c, bool jit) {
-    const size_t tiles = ((c->width + 7) / 8) * ((c->local_rows + 7) / 8);
+    const size_t tiles = ((c->width + 7) / 8) * ((c->local_rows + 7) / 8) * c->batch;
     // Four wavefronts per workgroup, and enough tiles per wavefront that starting it and having it
     // find every queue head dry at the end is small beside its work: a share of a frame (row bands
     // on 8 ranks) must not launch a wavefront per two tiles, and a smaller grid leaves room for the
@@ -312,7 +319,8 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
-    if (e == hipSuccess) e = hipMalloc(&c->fb, width * height * 4);
+    c->fb_bytes = width * height * 4;
+    if (e == hipSuccess) e = hipMalloc(&c->fb, c->fb_bytes);
     // a head sees about an eighth of the tiles: a quarter per list leaves room for imbalance,
     // and what does not fit goes to the overflow list, which can hold every tile
     c->overflow_cap = static_cast<uint32_t>(((width + 7) / 8) * ((height + 7) / 8));
@@ -412,14 +420,71 @@ int rm_set_nodes(rm_ctx* c, const rm_node* nodes, size_t n) {
     return upload_scene(c, nodes, n);
 }
 
-int rm_set_info(rm_ctx* c, const rm_rays_info* info) {
-    if (!c || !info) return RM_ERR_INVALID_ARG;
-    rm::Camera& k = c->cam;
+namespace {
+void camera_from(const rm_rays_info* info, rm::Camera& k) {
     k.depth = static_cast<float>(info->Depth);           // Source/cuda_kernels.cu:744
     const rm_point* src[5] = { &info->LightSource, &info->StartPos, &info->StartDir, &info->StartWVec, &info->StartHVec };
     float* dst[5] = { k.light, k.pos, k.dir, k.wvec, k.hvec };
     for (int i = 0; i < 5; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+}
+}  // namespace
+
+int rm_set_info(rm_ctx* c, const rm_rays_info* info) {
+    if (!c || !info) return RM_ERR_INVALID_ARG;
+    camera_from(info, c->cams[0]);
+    for (size_t f = 1; f < RM_MAX_BATCH; ++f) c->cams[f] = c->cams[0];      // every frame of a batch, until told otherwise
     c->have_info = true;
+    return RM_OK;
+}
+
+int rm_set_info_batch(rm_ctx* c, const rm_rays_info* infos, size_t n) {
+    if (!c || !infos || n == 0 || n > c->batch) return RM_ERR_INVALID_ARG;
+    for (size_t f = 0; f < n; ++f) camera_from(infos + f, c->cams[f]);
+    for (size_t f = n; f < RM_MAX_BATCH; ++f) c->cams[f] = c->cams[n - 1];
+    c->have_info = true;
+    return RM_OK;
+}
+
+int rm_set_batch(rm_ctx* c, size_t frames, size_t rgba_frame_stride_bytes, size_t luminance_frame_stride_bytes) {
+    if (!c || frames == 0 || frames > RM_MAX_BATCH) return RM_ERR_INVALID_ARG;
+    const size_t tiles = ((c->width + 7) / 8) * ((c->height + 7) / 8);
+    if (tiles * frames > (size_t(1) << 30)) return RM_ERR_INVALID_ARG;       // tile ids are 32-bit
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the scheduler's lists hold a launch's tiles; the context's own planes hold all its frames
+    if (frames != c->batch) {
+        const uint32_t overflow = static_cast<uint32_t>(tiles * frames);
+        const uint32_t list_cap = overflow / 4 + 16;
+        const size_t bytes = (3 * RM_SET_DWORDS + 3 * (static_cast<size_t>(RM_QUEUE_HEADS) * RM_COST_BUCKETS * list_cap + overflow)) *
+                             sizeof(uint32_t);
+        uint32_t* sched = nullptr;
+        HIP_TRY(hipMalloc(&sched, bytes));
+        hipError_t e = hipMemset(sched, 0, bytes);
+        if (e != hipSuccess) { (void)hipFree(sched); return static_cast<int>(e); }
+        (void)hipFree(c->sched);
+        c->sched = sched; c->overflow_cap = overflow; c->list_cap = list_cap;
+    } else {
+        HIP_TRY(hipMemset(c->sched, 0, 3 * RM_SET_DWORDS * sizeof(uint32_t)));
+    }
+    const size_t fb_need = c->width * c->height * 4 * frames;
+    if (fb_need > c->fb_bytes) {
+        uint8_t* fb = nullptr;
+        HIP_TRY(hipMalloc(&fb, fb_need));
+        if (c->out == c->fb) c->out = fb;
+        (void)hipFree(c->fb);
+        c->fb = fb; c->fb_bytes = fb_need;
+    }
+    if (c->hit && c->width * c->height * frames > c->hit_bytes) {
+        uint8_t* hit = nullptr;
+        HIP_TRY(hipMalloc(&hit, c->width * c->height * frames));
+        (void)hipFree(c->hit);
+        c->hit = hit; c->hit_bytes = c->width * c->height * frames;
+    }
+    c->batch = frames;
+    c->out_frame_stride = rgba_frame_stride_bytes;
+    c->lum_frame_stride = luminance_frame_stride_bytes;
+    c->history = false;
+    c->seq = 0;
     return RM_OK;
 }
 
@@ -445,7 +510,7 @@ int rm_local_rows(rm_ctx* c, size_t* rows) {
 int rm_enable_hit_mask(rm_ctx* c, int enable) {
     if (!c) return RM_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    if (enable && !c->hit) { HIP_TRY(hipMalloc(&c->hit, c->width * c->height)); }
+    if (enable && !c->hit) { c->hit_bytes = c->width * c->height * c->batch; HIP_TRY(hipMalloc(&c->hit, c->hit_bytes)); }
     if (!enable && c->hit) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->hit); c->hit = nullptr; }
     return RM_OK;
 }

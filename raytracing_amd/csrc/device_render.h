@@ -44,13 +44,13 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     scene.init(prm);
 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const P3 light{prm.cam.light[0], prm.cam.light[1], prm.cam.light[2]};
 
     // this frame found its scheduler set at zero; leave the next frame's at zero too
     if (blockIdx.x == 0 && threadIdx.x < RM_SET_LINES) prm.set_next[threadIdx.x * RM_QUEUE_STRIDE] = 0;
 
     const uint32_t tiles_x = (prm.width + 7) >> 3, tiles_y = (prm.local_rows + 7) >> 3;
-    const uint32_t ntiles = tiles_x * tiles_y;
+    const uint32_t ntiles_frame = tiles_x * tiles_y;
+    const uint32_t ntiles = ntiles_frame * prm.nframes;      // a launch of several frames (rm_set_batch) is one pool of tiles
     const uint32_t home = blockIdx.x & (RM_QUEUE_HEADS - 1);
     const bool ordered = prm.ordered != 0;
 
@@ -143,9 +143,13 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
 
     while (s_valid && !expired) {
         // ---- the next tile
-        const uint32_t tile = uniform(s_val);
+        const uint32_t tile_id = uniform(s_val);
         stage_s();
-        if (tile >= ntiles) continue;                // cannot happen with a sound list; never index past the image
+        if (tile_id >= ntiles) continue;             // cannot happen with a sound list; never index past the image
+        uint32_t frame = 0, tile = tile_id;
+        if (prm.nframes > 1) { frame = tile_id / ntiles_frame; tile = tile_id - frame * ntiles_frame; }
+        const Camera& cam = prm.cams[frame];
+        const P3 light{cam.light[0], cam.light[1], cam.light[2]};
         const uint32_t tile_y = tile / tiles_x;
         const uint32_t px = (tile - tile_y * tiles_x) * 8 + (lane & 7);      // column
         const uint32_t ly = tile_y * 8 + (lane >> 3);                        // row in the local buffer
@@ -154,7 +158,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         const bool in_image = px < prm.width && gy < prm.height && ly < prm.local_rows;
 
         P3 pos, rd;
-        make_ray(prm.cam, prm.width, prm.height, (int)px, (int)gy, pos, rd);
+        make_ray(cam, prm.width, prm.height, (int)px, (int)gy, pos, rd);
         float t = 0.f, cd = 0.f, n_l = 0.f, shadow = 1.f;
         int mode = in_image ? M_PRIMARY : M_DONE, steps = 0;
         bool need = false;                       // waiting for NORM(root, pos)
@@ -264,11 +268,11 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         if (expired) break;
 
         if (in_image) {                                                            // :717
-            *reinterpret_cast<uint32_t*>(prm.rgba + (size_t)ly * prm.pitch + (size_t)px * 4) = pixel;
-            if (prm.hit) prm.hit[(size_t)ly * prm.hit_pitch + (size_t)px] = (uint8_t)hit;
+            *reinterpret_cast<uint32_t*>(prm.rgba + frame * prm.frame_stride + (size_t)ly * prm.pitch + (size_t)px * 4) = pixel;
+            if (prm.hit) prm.hit[frame * prm.hit_frame_stride + (size_t)ly * prm.hit_pitch + (size_t)px] = (uint8_t)hit;
             // the luminance byte L of :694 is the blue channel (RM_MATERIAL_B is 1): a pixel is a function of L alone
             static_assert(RM_MATERIAL_B == 1.f, "the luminance plane reads L back from the blue channel");
-            if (prm.lum) prm.lum[(size_t)ly * prm.lum_pitch + (size_t)px] = (uint8_t)(pixel >> 16);
+            if (prm.lum) prm.lum[frame * prm.lum_frame_stride + (size_t)ly * prm.lum_pitch + (size_t)px] = (uint8_t)(pixel >> 16);
         }
 
         // ---- file the tile under its cost for the next frame
@@ -277,11 +281,11 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                              : trips >= 24 ? 4 : trips >= 12 ? 5 : trips >= 6 ? 6 : 7;
             const uint32_t at = uniform(bump(RM_SET_COUNT(home, b)));
             if (at < prm.list_cap) {
-                prm.lists_cur[(size_t)(home * RM_COST_BUCKETS + b) * prm.list_cap + at] = tile;    // every lane, same word
+                prm.lists_cur[(size_t)(home * RM_COST_BUCKETS + b) * prm.list_cap + at] = tile_id;    // every lane, same word
             } else {                                 // list full: the overflow list takes any tile
                 const uint32_t at2 = uniform(bump(RM_SET_OVERFLOW));
                 if (at2 < prm.overflow_cap)
-                    prm.lists_cur[(size_t)RM_QUEUE_HEADS * RM_COST_BUCKETS * prm.list_cap + at2] = tile;
+                    prm.lists_cur[(size_t)RM_QUEUE_HEADS * RM_COST_BUCKETS * prm.list_cap + at2] = tile_id;
             }
         }
     }

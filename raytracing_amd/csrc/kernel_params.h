@@ -22,6 +22,9 @@
 #define RM_SET_LINES       96
 #define RM_SET_DWORDS      (RM_SET_LINES * RM_QUEUE_STRIDE)
 
+// frames one launch may render (rm_set_batch): their cameras travel in the kernarg segment
+#define RM_MAX_BATCH 8
+
 namespace rm {
 
 // frames of the per-lane tree walker's private stack (>= scene_build.h kMaxTreeDepth)
@@ -45,6 +48,8 @@ struct RenderParams {
     uint32_t band_rows, rank, nranks;
     uint32_t norm_batch;          // lanes that must wait before normals are computed
     uint32_t evaluator;           // 0 distance program, 1 tree walker
+    uint32_t nframes;             // frames of this launch (rm_set_batch): tile ids run over all of them
+    size_t frame_stride, hit_frame_stride, lum_frame_stride;     // bytes from a frame's plane to the next frame's
     uint8_t* rgba;  size_t pitch;
     uint8_t* hit;   size_t hit_pitch;
     uint8_t* lum;   size_t lum_pitch;   // optional luminance plane, 1 B/px (rm_set_luminance_output)
@@ -60,7 +65,7 @@ struct RenderParams {
     uint32_t ordered;             // 1: hand out lists_prev; 0: no history, natural tile order
     uint32_t feedback;            // 1: write lists_cur
     uint32_t boost_age;           // loop trips after which a tile raises its wave's issue priority
-    Camera cam;
+    Camera cams[RM_MAX_BATCH];    // cams[f]: frame f of the launch
 };
 
 #ifndef __HIPCC_RTC__

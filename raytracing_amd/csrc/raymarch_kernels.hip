@@ -60,7 +60,7 @@ __global__ void eval_rays_kernel(const RenderParams prm, const int* __restrict__
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     P3 p, d;
-    make_ray(prm.cam, prm.width, prm.height, xy[2 * i], xy[2 * i + 1], p, d);
+    make_ray(prm.cams[0], prm.width, prm.height, xy[2 * i], xy[2 * i + 1], p, d);
     out[6 * i] = p.x; out[6 * i + 1] = p.y; out[6 * i + 2] = p.z;
     out[6 * i + 3] = d.x; out[6 * i + 4] = d.y; out[6 * i + 5] = d.z;
 }

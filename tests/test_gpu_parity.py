@@ -242,6 +242,62 @@ def test_luminance_planes_rebuild_the_frame(stock_scenes, name):
             rm.close()
 
 
+def test_batch_of_frames_in_one_launch(stock_scenes):
+    """rm_set_batch: several frames per launch, their tiles in one pool, equal the frames rendered one
+    by one: different cameras, caller-owned planes with a frame stride, row bands, three launches in a
+    row (natural order, then the tile order learnt from the launch before)."""
+    torch = pytest.importorskip("torch")
+    w, h, n = 200, 120, 3
+    infos = np.concatenate([O.default_info(k + 1, 7 * k) for k in range(n)])
+    nodes = stock_scenes["chair"]
+    for band, rank, nranks in [(0, 0, 1), (16, 1, 3)]:
+        singles, masks = [], []
+        with api.Raymarching(w, h) as rm:
+            rm.set_nodes(nodes)
+            rm.enable_hit_mask()
+            if band:
+                rm.set_bands(band, rank, nranks)
+            rows = rm.local_rows()
+            for k in range(n):
+                rm.set_info(infos[k:k + 1])
+                rm.process()
+                singles.append(rm.read_pixels())
+                masks.append(rm.read_hit_mask())
+        assert not np.array_equal(singles[0], singles[1])
+        stride, lstride = (rows + 3) * w * 4, (rows + 1) * w
+        out = torch.zeros((n, rows + 3, w, 4), dtype=torch.uint8, device="cuda")
+        lum = torch.zeros((n, rows + 1, w), dtype=torch.uint8, device="cuda")
+        with api.Raymarching(w, h) as rm:
+            rm.set_nodes(nodes)
+            if band:
+                rm.set_bands(band, rank, nranks)
+            rm.set_batch(n, stride, lstride)
+            rm.set_output(out.data_ptr(), w * 4)
+            rm.set_luminance_output(lum.data_ptr(), w)
+            rm.set_info_batch(infos)
+            for launch in range(3):
+                out.zero_()
+                rm.process()
+                got = out.cpu().numpy()
+                for k in range(n):
+                    assert np.array_equal(got[k, :rows], singles[k]), (band, launch, k)
+                    assert not got[k, rows:].any()
+                assert np.array_equal(lum.cpu().numpy()[:, :rows], got[:, :rows, :, 2])
+            # the context's own planes, packed, and the hit masks of frame 0
+            rm.set_batch(2)
+            rm.set_output(0, 0)
+            rm.set_luminance_output(0, 0)
+            rm.enable_hit_mask()
+            rm.set_info_batch(infos[1:3])
+            rm.process()
+            assert np.array_equal(rm.read_pixels(), singles[1])
+            assert np.array_equal(rm.read_hit_mask(), masks[1])
+            with pytest.raises(api.RaymarchError):
+                rm.set_batch(9)
+            with pytest.raises(api.RaymarchError):
+                rm.set_info_batch(infos)                 # three blocks for a batch of two
+
+
 def test_external_output_and_pitch(stock_scenes):
     """rm_set_output: render into a caller-owned device buffer with a padded pitch."""
     torch = pytest.importorskip("torch")

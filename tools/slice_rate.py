@@ -19,9 +19,10 @@ w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 216
 nodes = api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
 info = O.default_info(1, 0)
 band = tiling.default_band_rows(h, nranks) if nranks > 1 else 0
+batch = int(os.environ.get("SLICE_BATCH", "1"))        # frames per launch (rm_set_batch)
 
 
-def rate(k, frames=600):
+def rate(k, frames=600 // batch):
     ctxs, streams = [], []
     for _ in range(k):
         rm = api.Raymarching(w, h)
@@ -29,6 +30,8 @@ def rate(k, frames=600):
         rm.set_info(info)
         if band:
             rm.set_bands(band, 0, nranks)
+        if batch > 1:
+            rm.set_batch(batch)
         st = torch.cuda.Stream()
         rm.set_stream(st.cuda_stream)
         ctxs.append(rm)
@@ -44,11 +47,12 @@ def rate(k, frames=600):
     secs = time.perf_counter() - t0
     for rm in ctxs:
         rm.close()
-    return frames / secs, t_host / frames * 1e6
+    return frames * batch / secs, t_host / frames * 1e6
 
 
 whole = None
-print("GPU_MAX_HW_QUEUES=%s  %s %dx%d  %d ranks, bands of %d" % (os.environ.get("GPU_MAX_HW_QUEUES", "default"), scene, w, h, nranks, band))
+print("GPU_MAX_HW_QUEUES=%s  %s %dx%d  %d ranks, bands of %d, %d frame(s) per launch" %
+      (os.environ.get("GPU_MAX_HW_QUEUES", "default"), scene, w, h, nranks, band, batch))
 for k in (1, 2, 3, 4, 6, 8):
     fps, host_us = rate(k)
     print("  %d in flight: %8.0f band-sets/s  (%.1f us of host time per launch)" % (k, fps, host_us), flush=True)
