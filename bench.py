@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--workload", default="chair_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for N>1 (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the extra frame-per-launch measurement (profiling runs)")
     ap.add_argument("--norm-batch", type=int, default=0)
     ap.add_argument("--in-flight", type=int, default=0, help="contexts taking launches in turn (0 = 1 for N=1, 3 for N>1)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
@@ -339,7 +340,7 @@ def main():
                                        "(measured: tools/microbench/valu_peak.hip)",
                                "hbm": {"achieved": w * h * 4 / world * args.steps / launches / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "bytes_per_ray": 4}}
-        if world == 1 and batch > 1:
+        if world == 1 and batch > 1 and not args.no_single_frame:
             # the same frame one per launch, as the reference's Process() renders it
             with api.Raymarching(w, h, device=local_rank) as one:
                 one.set_nodes(nodes)

@@ -1,14 +1,14 @@
 #!/bin/bash
 # usage (GPU box, from the repo root): tools/profile_round.sh TAG
-# kernel trace + three counter passes of `bench.py --steps 30`, each its own rocprofv3 run; summaries into gpurun_out/TAG_*
+# kernel trace + four counter passes of bench.py (whole launches of 8 frames), each its own rocprofv3 run; summaries into gpurun_out/TAG_*
 tag=$1
 root=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 set -e
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/${tag}_trace -o t -- python3 $root/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $root/gpurun_out/${tag}_trace_bench.json
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/${tag}_trace -o t -- python3 $root/bench.py --steps 96 --warmup 16 --no-cpu-baseline --no-single-frame > $root/gpurun_out/${tag}_trace_bench.json
 for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
             "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE GRBM_COUNT" \
             "FETCH_SIZE" "WRITE_SIZE"; do
     name=$(echo $pass | cut -d' ' -f1)
-    timeout -s KILL 120 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $root/gpurun_out/${tag}_pmc_$name -o pmc -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null
+    timeout -s KILL 120 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $root/gpurun_out/${tag}_pmc_$name -o pmc -- python3 $root/bench.py --steps 24 --warmup 8 --no-cpu-baseline --no-single-frame > /dev/null
 done

@@ -14,15 +14,15 @@ tag = sys.argv[1]
 note = sys.argv[2] if len(sys.argv) > 2 else ""
 G = os.path.join(ROOT, "gpurun_out")
 KERNEL = "rm_render_jit"
-WARMUP = 5            # the counter passes run --steps 20 --warmup 5: launches before these are not averaged
+PMC_WARM_LAUNCHES, PMC_LAUNCHES = 1, 3      # the counter passes run --steps 24 --warmup 8 at 8 frames per launch
 
-lines = ["# %s: chair.sce 3840x2160, MI355X, one context, frames back to back%s" % (tag, (" -- " + note) if note else ""),
+lines = ["# %s: chair.sce 3840x2160, MI355X, one context, launches of 8 frames back to back; all figures per launch%s" % (tag, (" -- " + note) if note else ""),
          "# command per pass: rocprofv3 [--kernel-trace --stats | --pmc <counters> --kernel-trace] -- python3 bench.py --steps K --warmup W --no-cpu-baseline",
          "# (tools/profile_round.sh, summarised by tools/profile_summary.py; every counter pass is a run of its own)", ""]
 
 # ---- kernel trace
 db_path = glob.glob(os.path.join(G, tag + "_trace", "**", "*.db"), recursive=True)
-lines.append("## kernel trace (--steps 100 --warmup 10)")
+lines.append("## kernel trace (--steps 96 --warmup 16, 8 frames per launch)")
 avg_us = None
 if db_path:
     db = sqlite3.connect(db_path[0])
@@ -52,7 +52,7 @@ for path in sorted(glob.glob(os.path.join(G, tag + "_pmc_*", "**", "*counter_col
         per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
         per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     for name, by_dispatch in per.items():
-        vals = [v for _, v in sorted(by_dispatch.items())][WARMUP + 1:]      # +1: the parity frame
+        vals = [v for _, v in sorted(by_dispatch.items())][PMC_WARM_LAUNCHES:PMC_WARM_LAUNCHES + PMC_LAUNCHES]
         counters[name] = sum(vals) / len(vals)
 lines.append("## counters, mean per launch of %s over the timed launches (sum over the chip)" % KERNEL)
 for name, v in counters.items():
@@ -61,7 +61,8 @@ lines.append("")
 
 # ---- derived
 rec = json.loads(bench_line)
-rays = 3840 * 2160
+fpl = rec["config"].get("frames_per_launch", 1)
+rays = 3840 * 2160 * fpl                      # per launch
 lines.append("## derived")
 if "GRBM_GUI_ACTIVE" in counters:
     cyc = counters["GRBM_GUI_ACTIVE"] / 8
@@ -71,8 +72,7 @@ if "GRBM_GUI_ACTIVE" in counters:
         lines.append("wave-level VALU instructions per SIMD-cycle                  %10.3f  (v_add_f32 alone sustains 0.42: tools/microbench/valu_peak.hip)"
                      % (counters["SQ_INSTS_VALU"] / simd_cycles))
     if "SQ_ACTIVE_INST_VALU" in counters:
-        lines.append("VALU pipe busy (SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles)       %9.1f %%  (saturated; the counter's 4-cycle unit lets it pass 100)"
-                     % (400 * counters["SQ_ACTIVE_INST_VALU"] / simd_cycles))
+        lines.append("SQ_ACTIVE_INST_VALU per SIMD-cycle                           %10.3f" % (counters["SQ_ACTIVE_INST_VALU"] / simd_cycles))
 if "SQ_INSTS_VALU" in counters:
     lines.append("lane-level VALU instructions per ray                         %10.0f  (algorithmic FLOP per ray: %.0f)"
                  % (counters["SQ_INSTS_VALU"] * 64 / rays, rec["roofline"]["algorithmic_flops_per_ray"]))
@@ -83,8 +83,8 @@ if "WRITE_SIZE" in counters and "FETCH_SIZE" in counters:
     # MI355X_MICROARCH.md: both in KiB-like units of 1 KB per count here (rocprofv3 derived metric, KB); FETCH_SIZE x2 on gfx950
     wr, rd = counters["WRITE_SIZE"] * 1024, counters["FETCH_SIZE"] * 1024 * 2
     hbm = wr + rd
-    lines.append("HBM traffic per launch: WRITE_SIZE %.1f MB + FETCH_SIZE x2 %.1f MB (gfx950 correction of the guide); algorithmic: %.1f MB of pixels"
-                 % (wr / 1e6, rd / 1e6, rays * 4 / 1e6))
+    lines.append("HBM traffic per launch (%d frames): WRITE_SIZE %.1f MB + FETCH_SIZE x2 %.1f MB (gfx950 correction of the guide); algorithmic: %.1f MB of pixels"
+                 % (fpl, wr / 1e6, rd / 1e6, rays * 4 / 1e6))
 if avg_us is not None:
     lines.append("average kernel duration in the trace %.1f us; bench.py's own HIP-event average %.1f us" % (avg_us, rec["kernel_ms"] * 1e3))
 
