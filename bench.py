@@ -111,7 +111,6 @@ def main():
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for N>1 (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the extra frame-per-launch measurement (profiling runs)")
-    ap.add_argument("--norm-batch", type=int, default=0)
     ap.add_argument("--in-flight", type=int, default=0, help="contexts taking launches in turn (0 = 1 for N=1, 3 for N>1)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="frames whose tiles one launch pools (rm_set_batch), 1..8; 0 = 8")
@@ -166,8 +165,6 @@ def main():
         rm = api.Raymarching(w, h, device=local_rank)
         rm.set_nodes(nodes)
         rm.set_info(info)
-        if args.norm_batch:
-            rm.set_norm_batch(args.norm_batch)
         st = torch.cuda.Stream(device=dev)
         rm.set_stream(st.cuda_stream)
         ctxs.append(rm)

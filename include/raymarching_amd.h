@@ -199,11 +199,6 @@ int rm_jit_log(rm_ctx* ctx, char* buf, size_t cap);
  * large-scene form whatever the size (inspection only). */
 int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_source, char* text, size_t cap);
 
-/* Tuning: how many of a wavefront's lanes must be waiting for a surface normal
- * before the wave leaves the march loop to compute them (1..64).  Results do
- * not depend on it. */
-int rm_set_norm_batch(rm_ctx* ctx, int lanes);
-
 /* Arithmetic self-test (no counterpart in the reference).  The kernels take
  * sqrt and the divisions by scene constants through sequences a third as long
  * as the compiler's IEEE expansions (csrc/device_math.h: sqrt_exact, div_const)

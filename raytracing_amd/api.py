@@ -27,7 +27,7 @@ EXPORTS = [
     "rm_set_output", "rm_set_primitives", "rm_set_nodes", "rm_set_info", "rm_set_bands",
     "rm_local_rows", "rm_enable_hit_mask", "rm_process", "rm_process_async", "rm_synchronize",
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
-    "rm_flatten_scene", "rm_set_norm_batch", "rm_set_evaluator", "rm_status_string",
+    "rm_flatten_scene", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
     "rm_set_luminance_output", "rm_assemble_luminance", "rm_set_batch", "rm_set_info_batch",
 ]
@@ -94,7 +94,6 @@ def lib():
             "rm_device_framebuffer": [vp, C.POINTER(vp), C.POINTER(sz)],
             "rm_get_scene_stats": [vp, C.POINTER(SceneStats)],
             "rm_flatten_scene": [vp, sz, C.POINTER(SceneStats), C.c_char_p, sz],
-            "rm_set_norm_batch": [vp, i32],
             "rm_set_evaluator": [vp, i32],
             "rm_set_boost_age": [vp, C.c_uint],
             "rm_set_heavy_first": [vp, i32],
@@ -251,9 +250,6 @@ class Raymarching:
         buf = C.create_string_buffer(1 << 16)
         _check(lib().rm_jit_log(self._ctx, buf, 1 << 16), "rm_jit_log")
         return buf.value.decode(errors="replace")
-
-    def set_norm_batch(self, lanes):
-        _check(lib().rm_set_norm_batch(self._ctx, lanes), "rm_set_norm_batch")
 
     def set_heavy_first(self, enable=True):
         _check(lib().rm_set_heavy_first(self._ctx, 1 if enable else 0), "rm_set_heavy_first")

@@ -45,7 +45,7 @@ struct rm_ctx {
 
     size_t band_rows = 0; int rank = 0, nranks = 1;
     size_t local_rows = 0;
-    uint32_t norm_batch = 1, evaluator = 0;
+    uint32_t evaluator = 0;
     size_t lds_bytes = 0;
 
     // tile scheduler (device_render.h): three counter sets and three groups of tile lists used by
@@ -109,7 +109,6 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     p.band_rows = static_cast<uint32_t>(c->band_rows);
     p.rank = static_cast<uint32_t>(c->rank);
     p.nranks = static_cast<uint32_t>(c->nranks);
-    p.norm_batch = c->norm_batch;
     p.evaluator = c->evaluator;
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;
@@ -673,12 +672,6 @@ int rm_jit_check(const rm_node* nodes, size_t n, const char* arch, int want_sour
         text[k] = 0;
     }
     return ok ? RM_OK : RM_ERR_JIT;
-}
-
-int rm_set_norm_batch(rm_ctx* c, int lanes) {
-    if (!c || lanes < 1 || lanes > 64) return RM_ERR_INVALID_ARG;
-    c->norm_batch = static_cast<uint32_t>(lanes);
-    return RM_OK;
 }
 
 int rm_set_heavy_first(rm_ctx* c, int enable) {

@@ -249,10 +249,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             // Lanes that reached a surface take their normal in the same trip, at the point the
             // distance was just evaluated at (a waiting lane does not move): the normal's transforms
             // and child distances are the ones computed above, and the compiler shares them.
-            const unsigned long long nmask = __builtin_amdgcn_ballot_w64(need);
-            if (nmask == 0) continue;
-            const unsigned long long run = __builtin_amdgcn_ballot_w64((mode != M_DONE) && !need);
-            if (run != 0 && (uint32_t)__builtin_popcountll(nmask) < prm.norm_batch) continue;
+            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
             const uint64_t st_n0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
             ++st_norms;
             if (need) {                                                            // :635-637, :668-670

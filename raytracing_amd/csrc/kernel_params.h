@@ -46,7 +46,6 @@ struct RenderParams {
     uint32_t width, height;       // whole image
     uint32_t local_rows;          // rows this context renders
     uint32_t band_rows, rank, nranks;
-    uint32_t norm_batch;          // lanes that must wait before normals are computed
     uint32_t evaluator;           // 0 distance program, 1 tree walker
     uint32_t nframes;             // frames of this launch (rm_set_batch): tile ids run over all of them
     size_t frame_stride, hit_frame_stride, lum_frame_stride;     // bytes from a frame's plane to the next frame's

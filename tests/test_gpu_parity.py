@@ -46,7 +46,7 @@ def same_floats(a, b):
 PATHS = {"jit": (2, 0), "jitprog": (3, 0), "program": (0, 0), "walker": (0, 1)}
 
 
-def gpu_render(nodes, w, h, info, path="jit", norm_batch=None):
+def gpu_render(nodes, w, h, info, path="jit"):
     jit, evaluator = PATHS[path]
     with api.Raymarching(w, h) as rm:
         rm.set_jit(jit)
@@ -55,8 +55,6 @@ def gpu_render(nodes, w, h, info, path="jit", norm_batch=None):
         rm.set_info(info)
         rm.enable_hit_mask(True)
         rm.set_evaluator(evaluator)
-        if norm_batch is not None:
-            rm.set_norm_batch(norm_batch)
         ms = rm.process()
         return rm.read_pixels(), rm.read_hit_mask(), ms
 
@@ -139,14 +137,6 @@ def test_stock_hits_1080p(stock_scenes, name, path):
         ref = O.render(stock_scenes[name], 1920, 1080, info, rows=(y0, y0 + 1))
         assert np.array_equal(rgba[y0], ref["rgba"][y0]), y0
         assert np.array_equal(hit[y0], ref["hit"][y0]), y0
-
-
-def test_norm_batch_does_not_change_pixels(stock_scenes):
-    info = O.default_info(1, 0)
-    base, hit0, _ = gpu_render(stock_scenes["chair"], 320, 240, info, norm_batch=1)
-    for batch in (8, 64):
-        rgba, hit, _ = gpu_render(stock_scenes["chair"], 320, 240, info, norm_batch=batch)
-        assert np.array_equal(rgba, base) and np.array_equal(hit, hit0)
 
 
 def test_csg1024_frame():

@@ -19,8 +19,6 @@ def time_it(nodes, w, h, info, reps=7, jit=1, **knobs):
         rm.set_info(info)
         if "evaluator" in knobs:
             rm.set_evaluator(knobs["evaluator"])
-        if "norm_batch" in knobs:
-            rm.set_norm_batch(knobs["norm_batch"])
         if "heavy" in knobs:
             rm.set_heavy_first(bool(knobs["heavy"]))
         if "boost" in knobs:
@@ -46,8 +44,6 @@ def main():
             line += " ba%d %.3f" % (ba if ba < 1000 else -1, time_it(scenes[name], w, h, info, boost=ba))
         line += " | heavy0 %.3f heavy0,ba-1 %.3f |" % (time_it(scenes[name], w, h, info, heavy=0),
                                                       time_it(scenes[name], w, h, info, heavy=0, boost=0xffffffff))
-        for nb in (2, 8, 64):
-            line += " nb%d %.3f" % (nb, time_it(scenes[name], w, h, info, norm_batch=nb))
         if name != "csg1024":
             line += " | program %.3f" % time_it(scenes[name], w, h, info, reps=3, jit=0)
         print(line, flush=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave diagnostics of a frame: wave_stats.py SCENE W H [norm_batch]"""
+"""Per-wave diagnostics of a frame: wave_stats.py SCENE W H"""
 import os
 import sys
 
@@ -16,8 +16,6 @@ if os.environ.get("RM_JIT"): print("RM_JIT", os.environ["RM_JIT"])
 with api.Raymarching(w, h) as rm:
     rm.set_nodes(nodes)
     rm.set_info(O.default_info(1, 0))
-    if len(sys.argv) > 4:
-        rm.set_norm_batch(int(sys.argv[4]))
     ms = rm.process()
     st = rm.wave_stats().astype(np.float64)
 ev, nm, cyc, ncyc = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
