@@ -161,10 +161,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         make_ray(cam, prm.width, prm.height, (int)px, (int)gy, pos, rd);
         float t = 0.f, cd = 0.f, n_l = 0.f, shadow = 1.f;
         int mode = in_image ? M_PRIMARY : M_DONE, steps = 0;
-        bool need = false;                       // waiting for NORM(root, pos)
         uint32_t pixel = 0xff000000u, hit = 0;   // Source/cuda_kernels.cu:622
         uint32_t trips = 0;                      // loop trips of this tile: its cost
         bool boosted = false;
+        uint32_t next_check = prm.boost_age < 1023 ? prm.boost_age + 1 : 1024;
 
         // the two places a normal is consumed (Source/cuda_kernels.cu:640-658 and :673-691)
         auto advance_primary = [&]() {                                             // :707-714
@@ -216,13 +216,19 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         };
 
         for (;;) {
-            ++trips;
-            if ((trips & 0x3ff) == 0 && __builtin_amdgcn_s_memtime() - t_enter > (1ull << 36)) { expired = true; break; }
-            // a tile that runs long goes first on its SIMD: the long tiles set the length of the frame
-            if (trips > prm.boost_age && !boosted) { __builtin_amdgcn_s_setprio(3); boosted = true; }
+            // One compare per trip for the two things that happen rarely: a tile that runs long goes
+            // first on its SIMD from trip boost_age + 1 on (the long tiles set the length of the frame),
+            // and the watchdog looks at the clock every 1024 trips.
+            if (++trips == next_check) {
+                if (trips > prm.boost_age && !boosted) { __builtin_amdgcn_s_setprio(3); boosted = true; }
+                if (__builtin_amdgcn_s_memtime() - t_enter > (1ull << 36)) { expired = true; break; }
+                next_check = trips + 1024;
+                if (!boosted && prm.boost_age >= trips && prm.boost_age - trips < 1024) next_check = prm.boost_age + 1;
+            }
 
-            const bool active = (mode != M_DONE) && !need;
-            if (__builtin_amdgcn_ballot_w64(active) == 0) break;      // no lane waits for a normal here (below)
+            const bool active = mode != M_DONE;
+            if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+            bool need = false;                       // this lane wants NORM(root, pos) before it goes on
             ++st_evals;
             // DIST(root, pos) for the whole wave (:627 and :661 share this)
             const P3 at = pos;
@@ -257,7 +263,6 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 float R_1 = r_length_3(N.x, N.y, N.z);
                 P3 n{R_1 * N.x, R_1 * N.y, R_1 * N.z};
                 if (mode == M_PRIMARY) primary_normal(n); else shadow_normal(n);
-                need = false;
             }
             if (prm.wave_stats) st_norm_cycles += (uint32_t)(__builtin_amdgcn_s_memtime() - st_n0);
         }

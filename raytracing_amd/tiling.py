@@ -68,3 +68,16 @@ def assemble(parts, height, band_rows):
             frame[y0:y1] = parts[r][at:at + (y1 - y0)]
             at += y1 - y0
     return frame
+
+
+def expand_luminance(lum):
+    """Host mirror of rm_assemble_luminance's pixel: luminance plane [H, W] u8 -> RGBA8 [H, W, 4],
+    the material scaling of Source/cuda_kernels.cu:695-699 in fp32 (0.5, 0.7, 1.0; alpha 255)."""
+    import numpy as np
+    L = np.asarray(lum, dtype=np.uint8).astype(np.float32)
+    out = np.empty(L.shape + (4,), dtype=np.uint8)
+    out[..., 0] = (L * np.float32(0.5)).astype(np.uint8)          # truncation, as the kernel's cast
+    out[..., 1] = (L * np.float32(0.7)).astype(np.uint8)
+    out[..., 2] = L.astype(np.uint8)
+    out[..., 3] = 255
+    return out

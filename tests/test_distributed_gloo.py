@@ -1,6 +1,7 @@
 """CPU suite, world_size 2 over gloo: the N>1 path of bench.py (row bands per rank,
-gather to rank 0, one strided interleave) with the CPU restatement standing in for
-the render kernel.  The assembled frame must equal the single-rank frame byte for byte."""
+gather to rank 0, interleave) with the CPU restatement standing in for the render
+kernel.  The assembled frame must equal the single-rank frame byte for byte, both when
+RGBA8 rows travel and when the luminance planes of a launch of two frames do."""
 import os
 import socket
 import sys
@@ -45,6 +46,22 @@ def _worker(rank, world, port, w, h, band, out_path):
         frame = torch.zeros((tiling.padded_rows(h, band, world), w, 4), dtype=torch.uint8)
         tiling.assemble_into(frame, parts, band)
         np.save(out_path, frame[:h].numpy())
+    # bench.py's transport: one byte per pixel (the blue channel is the luminance), the frames of a
+    # launch in one gather, RGBA8 rebuilt on rank 0 (rm_set_luminance_output / rm_assemble_luminance)
+    infos = [info, O.default_info(3, 40)]
+    slab = torch.zeros((len(infos), rows_max, w), dtype=torch.uint8)
+    for f, inf in enumerate(infos):
+        at = 0
+        for y0, y1 in tiling.band_of_rank(h, band, rank, world):
+            part = O.render(nodes, w, h, inf, rows=(y0, y1))["rgba"][y0:y1]
+            slab[f, at:at + (y1 - y0)] = torch.from_numpy(np.ascontiguousarray(part[:, :, 2]))
+            at += y1 - y0
+    slabs = torch.zeros((world,) + tuple(slab.shape), dtype=torch.uint8) if rank == 0 else None
+    dist.gather(slab, list(slabs.unbind(0)) if rank == 0 else None, dst=0)
+    if rank == 0:
+        frames = [tiling.expand_luminance(tiling.assemble([slabs[r, f].numpy()[:, :, None] for r in range(world)], h, band)[:, :, 0])
+                  for f in range(len(infos))]
+        np.save(out_path.replace(".npy", "_lum.npy"), np.stack(frames))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,3 +74,6 @@ def test_two_rank_frame_equals_one_rank_frame(tmp_path, w, h, band):
     nodes = O.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", "chair.sce"))
     want = O.render(nodes, w, h, O.default_info(1, 0))["rgba"]
     assert np.array_equal(np.load(out), want)
+    got = np.load(out.replace(".npy", "_lum.npy"))
+    assert np.array_equal(got[0], want)
+    assert np.array_equal(got[1], O.render(nodes, w, h, O.default_info(3, 40))["rgba"])

@@ -17,6 +17,7 @@ from oracle import oracle as O
 from raytracing_amd import api, scenes
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # sha256 of the P6 PPM the reference's march produced host-side
 GOLDEN_PPM = {
@@ -449,3 +450,27 @@ def test_front_end_ppm_matches_reference_hash(name, golden_dir, tmp_path):
     assert run.returncode == 0, run.stderr + run.stdout
     with open(out, "rb") as f:
         assert hashlib.sha256(f.read()).hexdigest() == GOLDEN_PPM[name]
+
+
+def test_bench_two_ranks_on_one_gpu(golden_dir):
+    """bench.py's N>1 path end to end, two ranks sharing this GPU (RM_BENCH_REHEARSAL: gloo gather
+    through host copies instead of RCCL): launches of several frames, luminance planes gathered,
+    frames rebuilt on rank 0; a last launch that is not full.  The frame must be the golden one."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RM_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "13", "--warmup", "3",
+           "--frames-per-launch", "4", "--workload", "chair_1080p", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 13 and rec["launches"] == 4
+    assert rec["parity"]["frame_matches_golden"] is True
