@@ -102,7 +102,7 @@ __device__ __forceinline__ uint32_t exec_slot(Machine& m, const u32x8 w, float* 
         break;
     }
     case OP_CULL:                  // scene_program.h; lanes that do not march have no say
-        if (cull_all(S, (w0 & F_NEG) ? -m.A : m.A, active, f1, f2, f3, f4)) skip = w[5];
+        if (cull_all(S, (w0 & F_NEG) ? -m.A : m.A, (unsigned long long)__builtin_amdgcn_ballot_w64(active), f1, f2, f3, f4)) skip = w[5];
         break;
     case OP_PORTANTA_END: {
         float d = stack[slot * RM_BLOCK_THREADS];

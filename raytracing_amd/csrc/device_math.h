@@ -105,15 +105,16 @@ __device__ __forceinline__ float glata(float d0, float d1, float k, float rk, bo
     return h > 1.f ? d0 : (h < 0.f ? d1 : blended);
 }
 
-// OP_CULL (scene_program.h): true if no marching lane of the wave can be nearer to the group
-// inside the sphere (centre c, k = radius + margin) than its running minimum A
-__device__ __forceinline__ bool cull_all(P3 S, float A, bool active, float cx, float cy, float cz, float k) {
+// OP_CULL (scene_program.h): true if no marching lane of the wave (amask: their ballot) can be
+// nearer to the group inside the sphere (centre c, k = radius + margin) than its running minimum A
+__device__ __forceinline__ bool cull_all(P3 S, float A, unsigned long long amask, float cx, float cy, float cz, float k) {
     const float dx = S.x - cx, dy = S.y - cy, dz = S.z - cz;
     const float s2 = dx * dx + dy * dy + dz * dz, T = A + k;
-    const bool far = T < 0.f || s2 > T * T * 1.001953125f;      // false for NaN: never culls
-    return __builtin_amdgcn_ballot_w64(active && !far) == 0;
+    // a lane is near unless T < 0 or s2 > T^2 (1 + 2^-9) (near for NaN: never culls).  Two compares
+    // straight into scalar masks: a ballot of a combined predicate costs two more vector instructions.
+    const unsigned long long near = __builtin_amdgcn_ballot_w64(!(T < 0.f)) & __builtin_amdgcn_ballot_w64(!(s2 > T * T * 1.001953125f));
+    return (near & amask) == 0;
 }
-
 // ---- transforms (Source/cuda_kernels.cu:409-413,430-432,454-456,478-480,527-530,577-581)
 
 __device__ __forceinline__ P3 movo(P3 p, float tx, float ty, float tz) { return P3{p.x - tx, p.y - ty, p.z - tz}; }

@@ -505,8 +505,11 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
                 return;
             }
             const std::string rk = std::to_string((*ranks)[static_cast<size_t>((*slot_node)[pc])]) + "u";
+            // the two constants go through an opaque asm: the compiler would otherwise keep every
+            // member's pair in registers of their own for the whole kernel (190 VGPRs on config 4)
             s += pad + "{ const float v = " + neg + call + "; const bool take = v < A || (v == A && " + rk + " > brank); " +
-                 "A = take ? v : A; best = take ? " + std::to_string(pc) + "u : best; brank = take ? " + rk + " : brank; }\n";
+                 "uint32_t id = " + std::to_string(pc) + "u, rk = " + rk + "; asm volatile(\"\" : \"+v\"(id), \"+v\"(rk)); " +
+                 "A = take ? v : A; best = take ? id : best; brank = take ? rk : brank; }\n";
         };
         const std::string moved = "movo(" + S + ", " + f1 + ", " + f2 + ", " + f3 + ")";
         switch (op) {
@@ -559,7 +562,7 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
         case OP_PORTANTA_END: s += pad + "A = (" + V + " <= RM_MIN_DIST) ? A : " + V + ";\n"; a_inf = false; break;
         case OP_CULL: {                // scene_program.h
             const size_t skip = sl.w[5];
-            s += pad + "if (!cull_all(" + S + ", " + ((w0 & F_NEG) ? "-A" : "A") + ", active, " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ")) {\n";
+            s += pad + "if (!cull_all(" + S + ", " + ((w0 & F_NEG) ? "-A" : "A") + ", amask, " + f1 + ", " + f2 + ", " + f3 + ", " + f4 + ")) {\n";
             emit_range(prog, pc + 1, pc + 1 + skip, s, indent + 1, a_inf, slot_node, ranks);
             s += pad + "}\n";
             pc += skip;
@@ -571,9 +574,95 @@ void emit_range(const std::vector<Slot>& prog, size_t lo, size_t hi, std::string
     }
 }
 
+// [lo, hi) slot ranges of the groups a union's program splits into a few levels down its
+// bounding-sphere hierarchy (a range is one OP_CULL with everything it guards, or one primitive),
+// and where the transforms in front of the union end.  Empty if the program is not of that form.
+struct UnionGroups { size_t prefix_end = 0; std::vector<std::pair<size_t, size_t>> ranges; };
+UnionGroups union_groups(const std::vector<Slot>& prog) {
+    UnionGroups u;
+    auto op_of = [&](size_t pc) { return prog[pc].w[0] & 0xff; };
+    auto is_member = [&](size_t pc) { const uint32_t op = op_of(pc); return op == OP_CULL || (op >= OP_SFERO && op <= OP_EBENO); };
+    size_t end = 0;
+    while (end < prog.size() && op_of(end) != OP_END) ++end;
+    while (u.prefix_end < end && !is_member(u.prefix_end)) ++u.prefix_end;
+    for (size_t pc = u.prefix_end; pc < end; ++pc) if (!is_member(pc)) return UnionGroups();     // something else than one union
+    // split the widest range until there are enough groups (or nothing left to split)
+    std::vector<std::pair<size_t, size_t>> r;
+    auto items = [&](size_t lo, size_t hi, std::vector<std::pair<size_t, size_t>>& out) {
+        for (size_t pc = lo; pc < hi;) {
+            const size_t len = op_of(pc) == OP_CULL ? 1 + prog[pc].w[5] : 1;
+            out.emplace_back(pc, pc + len);
+            pc += len;
+        }
+    };
+    items(u.prefix_end, end, r);
+    while (r.size() < 12) {
+        size_t widest = r.size(), width = 4;                 // a group of fewer than 4 slots is not worth opening
+        for (size_t k = 0; k < r.size(); ++k)
+            if (op_of(r[k].first) == OP_CULL && r[k].second - r[k].first > width) { widest = k; width = r[k].second - r[k].first; }
+        if (widest == r.size()) break;
+        std::vector<std::pair<size_t, size_t>> inner;
+        items(r[widest].first + 1, r[widest].second, inner);
+        r.erase(r.begin() + static_cast<long>(widest));
+        r.insert(r.begin() + static_cast<long>(widest), inner.begin(), inner.end());
+    }
+    if (r.size() >= 4) u.ranges = r;
+    return u;
+}
+
+// A union of many primitives, its groups visited in an order that changes from call to call: the
+// group that held the minimum for the wave's first marching lane last time goes first, the others
+// follow in program order.  A ray moves little between two evaluations, so the first group leaves the
+// running minimum small and the bounding-sphere tests of most others pass at once (simulated on
+// config 4: 56 -> 19 primitives and 69 -> 35 tests per evaluation).  min() over the same members in
+// another order: the same value.  The groups are the cases of one switch inside a loop, so each is
+// compiled once; `first` lives in the scene's scratch (wave-uniform).
+// select: the normal's pass (scene_norm), which also tracks the winning member.
+std::string grouped_function(const std::vector<Slot>& program, const UnionGroups& u, bool select,
+                             const std::vector<int32_t>* slot_node, const std::vector<uint32_t>* ranks) {
+    std::string s = select ? "__device__ __forceinline__ uint32_t scene_pick(P3 E, uint32_t first, P3& F, float& Aout) {\n"
+                           : "__device__ __forceinline__ float scene_program(P3 E, bool active, uint32_t& first) {\n";
+    if (select) s += "    const bool active = true;     // called by the lanes that need a normal: the others are masked off\n    F = E;\n";
+    else s += "    P3 F = E;\n";
+    s += "    P3 P = E; float A = __builtin_inff(), tx = 0.f, ty = 0.f;\n";
+    s += "    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);\n";
+    if (select) s += "    uint32_t best = 0u, brank = 0u;\n";
+    else s += "    uint32_t bestg = first;\n";
+    bool a_inf = false;
+    emit_range(program, 0, u.prefix_end, s, 1, a_inf, slot_node, ranks);
+    const std::string G = std::to_string(u.ranges.size());
+    s += "#pragma clang loop unroll(disable)\n";       // one copy of every group, reached through the switch
+    s += "    for (uint32_t i = 0; i < " + G + "u; ++i) {\n";
+    s += "        const uint32_t g = i == 0 ? first : (i <= first ? i - 1 : i);\n";
+    // every member's distance depends on the point alone, so the compiler would compute all of them in
+    // front of the loop and keep them in registers: the point is made opaque once per trip
+    s += "        P3 Fi = F;\n        asm volatile(\"\" : \"+v\"(Fi.x), \"+v\"(Fi.y), \"+v\"(Fi.z));\n";
+    if (!select) s += "        const float before = A;\n";
+    s += "        {\n        const P3 F = Fi;\n";
+    s += "        switch (g) {\n";
+    for (size_t k = 0; k < u.ranges.size(); ++k) {
+        s += "        case " + std::to_string(k) + "u: {\n";
+        a_inf = false;
+        emit_range(program, u.ranges[k].first, u.ranges[k].second, s, 3, a_inf, slot_node, ranks);
+        s += "        } break;\n";
+    }
+    s += "        default: break;\n        }\n        }\n";
+    if (!select) s += "        bestg = A < before ? g : bestg;\n";
+    s += "    }\n";
+    if (select) {
+        s += "    (void)tx; (void)ty; (void)P; (void)brank;\n    Aout = A;\n    return best;\n}\n";
+    } else {
+        s += "    // the next call starts with the group that holds the minimum of the first marching lane\n";
+        s += "    first = (uint32_t)__builtin_amdgcn_readlane((int)bestg, (int)__builtin_ctzll(amask));\n";
+        s += "    (void)tx; (void)ty; (void)P;\n    return A;\n}\n";
+    }
+    return s;
+}
+
 std::string program_function(const std::vector<Slot>& program, uint32_t value_slots) {
     std::string s = "__device__ __forceinline__ float scene_program(P3 E, bool active) {\n";
     s += "    P3 F = E, P = E; float A = __builtin_inff(), B = 0.f, tx = 0.f, ty = 0.f;\n";
+    s += "    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);\n";
     if (value_slots) {
         s += "    float";
         for (uint32_t k = 0; k < value_slots; ++k) s += std::string(k ? "," : "") + " s" + std::to_string(k) + " = 0.f";
@@ -581,7 +670,7 @@ std::string program_function(const std::vector<Slot>& program, uint32_t value_sl
     }
     bool a_inf = true;
     emit_range(program, 0, program.size(), s, 1, a_inf);
-    s += "    (void)B; (void)tx; (void)ty; (void)F; (void)P; (void)active;\n    return A;\n}\n";
+    s += "    (void)B; (void)tx; (void)ty; (void)F; (void)P; (void)amask;\n    return A;\n}\n";
     return s;
 }
 
@@ -589,7 +678,10 @@ std::string program_function(const std::vector<Slot>& program, uint32_t value_sl
 
 std::string generate_program_source(const std::vector<Slot>& program, uint32_t value_slots,
                                     const std::vector<int32_t>& slot_node, const std::vector<uint32_t>& union_rank) {
-    std::string s = "namespace rm {\n" + program_function(program, value_slots);
+    const UnionGroups groups = union_rank.empty() ? UnionGroups() : union_groups(program);
+    const bool grouped = !groups.ranges.empty();
+    std::string s = "namespace rm {\n";
+    s += grouped ? grouped_function(program, groups, false, nullptr, nullptr) : program_function(program, value_slots);
 
     if (union_rank.empty()) {
         // normals by the tree walker over the LDS tree table: a normal function per node would
@@ -618,12 +710,20 @@ struct JitScene {
     // reference's nested kunigajo_N do.  One pass over the members, culled like the distance
     // program (a culled group is farther than A by a margin: it holds neither the minimum nor a
     // tie), then the winner's own normal, carried back through the rotations above the union.
-    s += "__device__ __forceinline__ P3 scene_norm(P3 E) {\n";
-    s += "    const bool active = true;     // called by the lanes that need a normal: the others are masked off\n";
-    s += "    P3 F = E, P = E; float A = __builtin_inff(), tx = 0.f, ty = 0.f; uint32_t best = 0u, brank = 0u;\n";
-    bool a_inf = true;
-    emit_range(program, 0, program.size(), s, 1, a_inf, &slot_node, &union_rank);
-    s += "    (void)tx; (void)ty; (void)P; (void)brank;\n    P3 N{0.f, 0.f, 0.f};\n    switch (best) {\n";
+    if (grouped) {
+        s += grouped_function(program, groups, true, &slot_node, &union_rank);
+        s += "__device__ __forceinline__ P3 scene_norm(P3 E, uint32_t first) {\n";
+        s += "    P3 F; float A;\n    const uint32_t best = scene_pick(E, first, F, A);\n    (void)A;\n";
+        s += "    P3 N{0.f, 0.f, 0.f};\n    switch (best) {\n";
+    } else {
+        s += "__device__ __forceinline__ P3 scene_norm(P3 E, uint32_t) {\n";
+        s += "    const bool active = true;     // called by the lanes that need a normal: the others are masked off\n";
+        s += "    P3 F = E, P = E; float A = __builtin_inff(), tx = 0.f, ty = 0.f; uint32_t best = 0u, brank = 0u;\n";
+        s += "    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);\n";
+        bool a_inf = true;
+        emit_range(program, 0, program.size(), s, 1, a_inf, &slot_node, &union_rank);
+        s += "    (void)tx; (void)ty; (void)P; (void)brank; (void)amask;\n    P3 N{0.f, 0.f, 0.f};\n    switch (best) {\n";
+    }
     std::vector<std::string> back;            // rotations met on the way down, to undo on the way up
     for (size_t pc = 0; pc < program.size(); ++pc) {
         const Slot& sl = program[pc];
@@ -652,13 +752,14 @@ struct JitScene {
     s += "    default: break;\n    }\n";
     for (size_t k = back.size(); k-- > 0;) s += "    " + back[k] + "\n";
     s += "    return N;\n}\n";
-    s += R"(
+    s += std::string(R"(
 struct JitScene {
-    struct Scratch {};
+    struct Scratch { uint32_t first = 0; };      // the group to visit first (wave-uniform)
     __device__ __forceinline__ void init(const RenderParams&) {}
     struct Keep {};
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
-    __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep&) { return scene_norm(p); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch& st, bool active, Keep&) { return )") +
+         (grouped ? "scene_program(p, active, st.first)" : "scene_program(p, active)") + R"(; }
+    __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return scene_norm(p, st.first); }
 };
 }  // namespace rm
 )";
