@@ -96,6 +96,12 @@ def cpu_baseline(scene, w, h, info, want):
     out = {"value": w * h / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": "1 full %dx%d frame of %s.sce, rows dealt over %d threads" % (w, h, scene, threads),
            "seconds": r["seconds"], "flops": r["counters"]["flops"], "hits": r["counters"]["hits"]}
+    # one thread, on a band of 32 rows through the middle of the image (SURVEY.md 8d asks for both)
+    rows = (h // 2 - 16, h // 2 + 16)
+    t0 = time.perf_counter()
+    O.render(nodes, w, h, info, rows=rows)
+    out["one_thread"] = {"value": w * (rows[1] - rows[0]) / (time.perf_counter() - t0) / 1e6, "unit": "Mrays/s",
+                         "sample": "rows %d-%d of the same frame" % (rows[0], rows[1] - 1)}
     if want is not None:
         out["matches_golden_counters"] = (r["counters"]["flops"] == want["counters"]["flops"] and
                                           r["counters"]["hits"] == want["hits"])
