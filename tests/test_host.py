@@ -249,3 +249,21 @@ def test_tiling_partition_covers_every_row_once():
 
 def test_cpp_front_end_is_built():
     assert os.path.exists(os.path.join(ROOT, "raytracing_amd", "rm_render")), "run __graft_entry__.build()"
+
+
+@pytest.mark.parametrize("name", ["chair", "infinity", "carved", "deep_values", "portanta_nested", "csg1024"])
+def test_generated_code_compiles_for_gfx950_without_a_device(name, stock_scenes):
+    """rm_jit_check: the per-scene HIP source every generator writes (fused distance/normal pair, the
+    pair with a culled distance program, the grouped union of a large scene) goes through hiprtc
+    for gfx950 here, on a machine with no GPU."""
+    table = stock_scenes[name] if name in stock_scenes else (scenes.csg1024() if name == "csg1024" else kat_scenes.tables()[name])
+    rc, log = api.jit_check(table, want_source=False, assume_exact_divisors=True)
+    assert rc == 0, log[-2000:]
+    rc, src = api.jit_check(table, want_source=True, assume_exact_divisors=True, cap=1 << 22)
+    assert rc == 0
+    if name == "csg1024":         # one switch of compiled groups inside a loop, for distance and for the normal's pass
+        assert "scene_pick" in src and src.count("switch (g)") == 2 and "unroll(disable)" in src
+    elif "if (!cull_all(" in src:     # a distance program with bounding-sphere tests, normals from n0
+        assert name in ("carved", "deep_values") and "return n0(p)" in src and "struct SceneKeep" not in src
+    else:                             # the fused pair over kept temporaries
+        assert name != "carved" and "struct SceneKeep" in src and "scene_norm_keep" in src
