@@ -596,7 +596,10 @@ UnionGroups union_groups(const std::vector<Slot>& prog) {
         }
     };
     items(u.prefix_end, end, r);
-    while (r.size() < 12) {
+    size_t want = 12;
+    if (const char* env = std::getenv("RM_UNION_GROUPS"))        // experiments only
+        if (std::atoi(env) > 0) want = static_cast<size_t>(std::atoi(env));
+    while (r.size() < want) {
         size_t widest = r.size(), width = 4;                 // a group of fewer than 4 slots is not worth opening
         for (size_t k = 0; k < r.size(); ++k)
             if (op_of(r[k].first) == OP_CULL && r[k].second - r[k].first > width) { widest = k; width = r[k].second - r[k].first; }

@@ -126,6 +126,29 @@ def test_stock_frame_640x480(stock_scenes, name, path):
     assert np.array_equal(hit.astype(bool), rgba[:, :, :3].any(-1))
 
 
+def _golden_frames():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "frames.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("key", sorted(_golden_frames()))
+def test_committed_golden_frames(key, stock_scenes, golden_dir):
+    """Every frame tests/golden/make_goldens.py recorded from the oracle (configs 1-3 at full size, the
+    1024-node scene at 960x540): RGBA8 sha256, hit count, and the bit-packed hit mask, bit for bit."""
+    import zlib
+    rec = _golden_frames()[key]
+    name = key.rsplit("_", 1)[0]
+    w, h = rec["width"], rec["height"]
+    table = scenes.csg1024() if name == "csg1024" else stock_scenes[name]
+    rgba, hit, _ = gpu_render(table, w, h, O.default_info(1, 0))
+    assert int(hit.sum()) == rec["hits"]
+    assert hashlib.sha256(rgba.tobytes()).hexdigest() == rec["rgba_sha256"]
+    with open(os.path.join(golden_dir, "hit_%s.z" % key), "rb") as f:
+        want = np.frombuffer(zlib.decompress(f.read()), dtype=np.uint8)
+    assert np.array_equal(np.packbits(hit.astype(bool), axis=None), want)
+
+
 @pytest.mark.parametrize("name", ["chair", "infinity"])
 @pytest.mark.parametrize("path", ["jit", "program"])
 def test_stock_hits_1080p(stock_scenes, name, path):
