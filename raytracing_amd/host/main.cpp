@@ -3,7 +3,7 @@
 // call sequence (Source/main.cpp:67-138, 261-270, 292-293), with a PPM dump in
 // the place of the SDL window.
 //
-//   rm_render --width W --height H [--input scene.sce] [--frames K] [--out frame.ppm] [--device D]
+//   rm_render --width W --height H [--input scene.sce] [--frames K] [--drag-x PX] [--drag-y PX] [--out frame.ppm] [--device D]
 //
 // Without --input the scene hard-coded in Source/main.cpp:86-123 is built with
 // the same create_from calls.  Without --width/--height the reference takes the
@@ -21,6 +21,9 @@
 #include "rays.hpp"
 
 constexpr float M_SQRT1_5f{ .447213595499957939281f };   // Source/main.cpp:7
+#ifndef M_PI_2f
+constexpr float M_PI_2f{ 1.57079632679489661923f };
+#endif
 
 using namespace std;
 
@@ -39,6 +42,7 @@ static int write_ppm(const string& path, const vector<unsigned char>& rgba, size
 
 int main(int argc, char** argv) {
     size_t Width = 0, Height = 0, Frames = 1;
+    int DragX = 0, DragY = 0;          // scripted right-button drag per frame, pixels (Source/main.cpp:240-251)
     int Device = 0;
     string File, Out;
 
@@ -52,6 +56,8 @@ int main(int argc, char** argv) {
         else if (arg == "height")  { Height = atoi(argv[++I]); if (Height) correctInit ^= 1 << 1; }
         else if (arg == "input")   { File = argv[++I];         if (File.size()) correctInit ^= 1 << 2; }
         else if (arg == "frames")  { Frames = strtoul(argv[++I], nullptr, 10); }
+        else if (arg == "drag-x")  { DragX = atoi(argv[++I]); }
+        else if (arg == "drag-y")  { DragY = atoi(argv[++I]); }
         else if (arg == "out")     { Out = argv[++I]; }
         else if (arg == "device")  { Device = atoi(argv[++I]); }
     }
@@ -94,8 +100,8 @@ int main(int argc, char** argv) {
     }
 
     // Source/main.cpp:127-138
-    float scale = powf(2.f, -6.1f), cos_theta = 1.f, sin_theta = 0.f, cos_phi = 1.f, sin_phi = 0.f;
-    float cos_1 = cosf(M_PI / 180.f), sin_1 = sinf(M_PI / 180.f);
+    float scale = powf(2.f, -6.1f), theta = 0.f, cos_theta = 1.f, sin_theta = 0.f, phi = 0.f, cos_phi = 1.f, sin_phi = 0.f;
+    float cos_1 = cosf(M_PI / 180.f), sin_1 = sinf(M_PI / 180.f), deg = M_PI / 360.f;
     rays_info Info_h{};
     Info_h.Depth = 1000;
     Info_h.LightSource = point{ -2.f * M_SQRT1_5f, 0.f, M_SQRT1_5f };
@@ -109,6 +115,21 @@ int main(int argc, char** argv) {
     auto t0 = chrono::steady_clock::now();
     for (size_t frame = 0; frame < Frames; ++frame) {
         auto f0 = chrono::steady_clock::now();
+        // Source/main.cpp:240-255, scripted: from the second frame on the mouse has moved (DragX, DragY)
+        // pixels with the right button down since the frame before (--drag-x 1)
+        if (frame > 0 && (DragX || DragY)) {
+            theta += float(DragY) * deg;
+            if (theta > M_PI_2f) theta = M_PI_2f;
+            else if (theta < -M_PI_2f) theta = -M_PI_2f;
+            cos_theta = cosf(theta);
+            sin_theta = sinf(theta);
+            phi += float(DragX) * deg;
+            cos_phi = cosf(phi);
+            sin_phi = sinf(phi);
+            Info_h.StartDir = point{ scale * cos_theta * cos_phi, scale * cos_theta * sin_phi, scale * sin_theta };
+            Info_h.StartWVec = point{ scale * sin_phi, -scale * cos_phi, 0.f };
+            Info_h.StartHVec = point{ scale * sin_theta * cos_phi, scale * sin_theta * sin_phi, -scale * cos_theta };
+        }
         // Source/main.cpp:261-266: the light turns one degree before every render
         Info_h.LightSource = point{
             cos_1 * Info_h.LightSource.x - sin_1 * Info_h.LightSource.y,
