@@ -37,6 +37,18 @@ namespace rm {
 // is dry.  The queue runs two tiles ahead of the wave (counter value -> list
 // entry -> tile), so neither the atomic nor the dependent load is waited for.
 // =============================================================================
+// The launch parameters, read from the kernarg segment through a pointer the compiler cannot see
+// through: every call site loads what it needs there and then (scalar loads, once per tile), so
+// the two dozen pointers, pitches and sizes used between tiles do not sit in SGPRs during the
+// march - the scalar registers, not the vector ones, decide how many wavefronts a SIMD holds.
+// Only for kernels whose first argument is the RenderParams (the two render kernels).
+typedef const __attribute__((address_space(4))) RenderParams KernargParams;
+__device__ __forceinline__ KernargParams* kernarg_params() {
+    KernargParams* p = (KernargParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 template <class Scene>
 __device__ __forceinline__ void render_body(const RenderParams& prm) {
     Scene scene;
@@ -69,7 +81,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         uint32_t below;                              // lanes below this one: 0 in lane 0
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(below));
         uint32_t v = below;
-        if (below == 0) v = __hip_atomic_fetch_add(prm.set_cur + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (below == 0) v = __hip_atomic_fetch_add(kernarg_params()->set_cur + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     };
 
@@ -81,11 +93,14 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         a_head = a_cursor < RM_QUEUE_HEADS ? ((home + a_cursor) & (RM_QUEUE_HEADS - 1)) : RM_QUEUE_HEADS;
         if (ordered) {
             uint32_t sum = 0;
+            KernargParams* kp = kernarg_params();
+            const uint32_t* set_prev = kp->set_prev;
+            const uint32_t list_cap = kp->list_cap, overflow_cap = kp->overflow_cap;
 #pragma unroll
             for (int b = 0; b < RM_COST_BUCKETS; ++b) {
                 uint32_t n = 0;
-                if (a_head < RM_QUEUE_HEADS) n = min(prm.set_prev[RM_SET_COUNT(a_head, b)], prm.list_cap);
-                else if (b == 0)             n = min(prm.set_prev[RM_SET_OVERFLOW], prm.overflow_cap);
+                if (a_head < RM_QUEUE_HEADS) n = min(set_prev[RM_SET_COUNT(a_head, b)], list_cap);
+                else if (b == 0)             n = min(set_prev[RM_SET_OVERFLOW], overflow_cap);
                 sum += n;
                 a_cum[b] = sum;
             }
@@ -98,7 +113,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // A head that is already dry costs a load, not an atomic: at the end of a frame every wave
         // walks all the heads, and atomics on one word go through L2 one at a time (~88 per us).
         // The counter only grows, so a stale value can only send a wave to the atomic needlessly.
-        const uint32_t seen = uniform(__hip_atomic_load(prm.set_cur + RM_SET_PULL(a_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const uint32_t seen = uniform(__hip_atomic_load(kernarg_params()->set_cur + RM_SET_PULL(a_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         if (seen >= a_total) a_ticket = a_total;
         else a_ticket = bump(RM_SET_PULL(a_head));
     };
@@ -115,7 +130,8 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
 #pragma unroll
                     for (int k = 0; k + 1 < RM_COST_BUCKETS; ++k)
                         if (c >= a_cum[k]) { b = k + 1; base = a_cum[k]; }
-                    const uint32_t* list = prm.lists_prev + (size_t)(a_head * RM_COST_BUCKETS + b) * prm.list_cap;
+                    KernargParams* kp = kernarg_params();
+                    const uint32_t* list = kp->lists_prev + (size_t)(a_head * RM_COST_BUCKETS + b) * kp->list_cap;
                     s_val = __builtin_nontemporal_load(list + (c - base));
                 } else {
                     s_val = a_head + RM_QUEUE_HEADS * c;
@@ -147,24 +163,33 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         stage_s();
         if (tile_id >= ntiles) continue;             // cannot happen with a sound list; never index past the image
         uint32_t frame = 0, tile = tile_id;
-        if (prm.nframes > 1) { frame = tile_id / ntiles_frame; tile = tile_id - frame * ntiles_frame; }
-        const Camera& cam = prm.cams[frame];
+        KernargParams* tp = kernarg_params();           // this tile's view of the launch parameters
+        if (tp->nframes > 1) { frame = tile_id / ntiles_frame; tile = tile_id - frame * ntiles_frame; }
+        Camera cam;                                      // 16 dwords of scalar loads
+        {
+            const __attribute__((address_space(4))) float* src = reinterpret_cast<const __attribute__((address_space(4))) float*>(&tp->cams[frame]);
+            float* dst = reinterpret_cast<float*>(&cam);
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(Camera) / sizeof(float)); ++k) dst[k] = src[k];
+        }
         const P3 light{cam.light[0], cam.light[1], cam.light[2]};
         const uint32_t tile_y = tile / tiles_x;
         const uint32_t px = (tile - tile_y * tiles_x) * 8 + (lane & 7);      // column
         const uint32_t ly = tile_y * 8 + (lane >> 3);                        // row in the local buffer
         uint32_t gy = ly;                                                    // row in the image
-        if (prm.band_rows) gy = ((ly / prm.band_rows) * prm.nranks + prm.rank) * prm.band_rows + ly % prm.band_rows;
-        const bool in_image = px < prm.width && gy < prm.height && ly < prm.local_rows;
+        const uint32_t band_rows = tp->band_rows, width = tp->width, height = tp->height;
+        if (band_rows) gy = ((ly / band_rows) * tp->nranks + tp->rank) * band_rows + ly % band_rows;
+        const bool in_image = px < width && gy < height && ly < tp->local_rows;
 
         P3 pos, rd;
-        make_ray(cam, prm.width, prm.height, (int)px, (int)gy, pos, rd);
+        make_ray(cam, width, height, (int)px, (int)gy, pos, rd);
         float t = 0.f, cd = 0.f, n_l = 0.f, shadow = 1.f;
         int mode = in_image ? M_PRIMARY : M_DONE, steps = 0;
         uint32_t pixel = 0xff000000u, hit = 0;   // Source/cuda_kernels.cu:622
         uint32_t trips = 0;                      // loop trips of this tile: its cost
         bool boosted = false;
-        uint32_t next_check = prm.boost_age < 1023 ? prm.boost_age + 1 : 1024;
+        const uint32_t boost_age = tp->boost_age;
+        uint32_t next_check = boost_age < 1023 ? boost_age + 1 : 1024;
 
         // the two places a normal is consumed (Source/cuda_kernels.cu:640-658 and :673-691)
         auto advance_primary = [&]() {                                             // :707-714
@@ -220,10 +245,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             // first on its SIMD from trip boost_age + 1 on (the long tiles set the length of the frame),
             // and the watchdog looks at the clock every 1024 trips.
             if (++trips == next_check) {
-                if (trips > prm.boost_age && !boosted) { __builtin_amdgcn_s_setprio(3); boosted = true; }
+                if (trips > boost_age && !boosted) { __builtin_amdgcn_s_setprio(3); boosted = true; }
                 if (__builtin_amdgcn_s_memtime() - t_enter > (1ull << 36)) { expired = true; break; }
                 next_check = trips + 1024;
-                if (!boosted && prm.boost_age >= trips && prm.boost_age - trips < 1024) next_check = prm.boost_age + 1;
+                if (!boosted && boost_age >= trips && boost_age - trips < 1024) next_check = boost_age + 1;
             }
 
             const bool active = mode != M_DONE;
@@ -270,24 +295,26 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         if (expired) break;
 
         if (in_image) {                                                            // :717
-            *reinterpret_cast<uint32_t*>(prm.rgba + frame * prm.frame_stride + (size_t)ly * prm.pitch + (size_t)px * 4) = pixel;
-            if (prm.hit) prm.hit[frame * prm.hit_frame_stride + (size_t)ly * prm.hit_pitch + (size_t)px] = (uint8_t)hit;
+            KernargParams* ep = kernarg_params();
+            *reinterpret_cast<uint32_t*>(ep->rgba + frame * ep->frame_stride + (size_t)ly * ep->pitch + (size_t)px * 4) = pixel;
+            if (ep->hit) ep->hit[frame * ep->hit_frame_stride + (size_t)ly * ep->hit_pitch + (size_t)px] = (uint8_t)hit;
             // the luminance byte L of :694 is the blue channel (RM_MATERIAL_B is 1): a pixel is a function of L alone
             static_assert(RM_MATERIAL_B == 1.f, "the luminance plane reads L back from the blue channel");
-            if (prm.lum) prm.lum[frame * prm.lum_frame_stride + (size_t)ly * prm.lum_pitch + (size_t)px] = (uint8_t)(pixel >> 16);
+            if (ep->lum) ep->lum[frame * ep->lum_frame_stride + (size_t)ly * ep->lum_pitch + (size_t)px] = (uint8_t)(pixel >> 16);
         }
 
         // ---- file the tile under its cost for the next frame
-        if (prm.feedback) {
+        KernargParams* fp = kernarg_params();
+        if (fp->feedback) {
             const uint32_t b = trips >= 384 ? 0 : trips >= 192 ? 1 : trips >= 96 ? 2 : trips >= 48 ? 3
                              : trips >= 24 ? 4 : trips >= 12 ? 5 : trips >= 6 ? 6 : 7;
             const uint32_t at = uniform(bump(RM_SET_COUNT(home, b)));
-            if (at < prm.list_cap) {
-                prm.lists_cur[(size_t)(home * RM_COST_BUCKETS + b) * prm.list_cap + at] = tile_id;    // every lane, same word
+            if (at < fp->list_cap) {
+                fp->lists_cur[(size_t)(home * RM_COST_BUCKETS + b) * fp->list_cap + at] = tile_id;    // every lane, same word
             } else {                                 // list full: the overflow list takes any tile
                 const uint32_t at2 = uniform(bump(RM_SET_OVERFLOW));
-                if (at2 < prm.overflow_cap)
-                    prm.lists_cur[(size_t)RM_QUEUE_HEADS * RM_COST_BUCKETS * prm.list_cap + at2] = tile_id;
+                if (at2 < fp->overflow_cap)
+                    fp->lists_cur[(size_t)RM_QUEUE_HEADS * RM_COST_BUCKETS * fp->list_cap + at2] = tile_id;
             }
         }
     }
