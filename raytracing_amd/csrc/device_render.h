@@ -258,9 +258,8 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             // DIST(root, pos) for the whole wave (:627 and :661 share this)
             const P3 at = pos;
             typename Scene::Keep keep;
-            float d = scene.dist_keep(at, scratch, active, keep);
+            cd = scene.dist_keep(at, scratch, active, keep);     // every lane: nothing reads a resting lane's value
             if (active) {
-                cd = d;
                 if (mode == M_PRIMARY) {
                     if (cd < RM_MIN_DIST) {                                    // :629
                         if (cd < -0.f) primary_normal(P3{-rd.x, -rd.y, -rd.z});  // :630-633
