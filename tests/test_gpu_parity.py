@@ -281,35 +281,37 @@ def test_batch_of_frames_in_one_launch(stock_scenes):
         stride, lstride = (rows + 3) * w * 4, (rows + 1) * w
         out = torch.zeros((n, rows + 3, w, 4), dtype=torch.uint8, device="cuda")
         lum = torch.zeros((n, rows + 1, w), dtype=torch.uint8, device="cuda")
-        with api.Raymarching(w, h) as rm:
-            rm.set_nodes(nodes)
-            if band:
-                rm.set_bands(band, rank, nranks)
-            rm.set_batch(n, stride, lstride)
-            rm.set_output(out.data_ptr(), w * 4)
-            rm.set_luminance_output(lum.data_ptr(), w)
-            rm.set_info_batch(infos)
-            for launch in range(3):
-                out.zero_()
+        for jit_mode in (2, 0):                          # generated code, then the interpreter kernels
+            with api.Raymarching(w, h) as rm:
+                rm.set_jit(jit_mode)
+                rm.set_nodes(nodes)
+                if band:
+                    rm.set_bands(band, rank, nranks)
+                rm.set_batch(n, stride, lstride)
+                rm.set_output(out.data_ptr(), w * 4)
+                rm.set_luminance_output(lum.data_ptr(), w)
+                rm.set_info_batch(infos)
+                for launch in range(3):
+                    out.zero_()
+                    rm.process()
+                    got = out.cpu().numpy()
+                    for k in range(n):
+                        assert np.array_equal(got[k, :rows], singles[k]), (band, launch, k)
+                        assert not got[k, rows:].any()
+                    assert np.array_equal(lum.cpu().numpy()[:, :rows], got[:, :rows, :, 2])
+                # the context's own planes, packed, and the hit masks of frame 0
+                rm.set_batch(2)
+                rm.set_output(0, 0)
+                rm.set_luminance_output(0, 0)
+                rm.enable_hit_mask()
+                rm.set_info_batch(infos[1:3])
                 rm.process()
-                got = out.cpu().numpy()
-                for k in range(n):
-                    assert np.array_equal(got[k, :rows], singles[k]), (band, launch, k)
-                    assert not got[k, rows:].any()
-                assert np.array_equal(lum.cpu().numpy()[:, :rows], got[:, :rows, :, 2])
-            # the context's own planes, packed, and the hit masks of frame 0
-            rm.set_batch(2)
-            rm.set_output(0, 0)
-            rm.set_luminance_output(0, 0)
-            rm.enable_hit_mask()
-            rm.set_info_batch(infos[1:3])
-            rm.process()
-            assert np.array_equal(rm.read_pixels(), singles[1])
-            assert np.array_equal(rm.read_hit_mask(), masks[1])
-            with pytest.raises(api.RaymarchError):
-                rm.set_batch(9)
-            with pytest.raises(api.RaymarchError):
-                rm.set_info_batch(infos)                 # three blocks for a batch of two
+                assert np.array_equal(rm.read_pixels(), singles[1])
+                assert np.array_equal(rm.read_hit_mask(), masks[1])
+                with pytest.raises(api.RaymarchError):
+                    rm.set_batch(9)
+                with pytest.raises(api.RaymarchError):
+                    rm.set_info_batch(infos)                 # three blocks for a batch of two
 
 
 def test_external_output_and_pitch(stock_scenes):
