@@ -68,25 +68,38 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
 
     // ---- tile queue (wave-uniform; values that come from memory sit in a VGPR until they are needed)
     auto uniform = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    // One lane bumps a counter for the wave.  Two things about this build keep that honest:
-    //  * the lane index is taken by an asm the compiler cannot see through, afresh for every
-    //    call.  With a plain `if (lane == 0)` it threads the branch through the cross-lane
-    //    reads that follow and splits the wave into a lane-0 path and a path of the other
-    //    lanes, each with a queue state of its own (and the other lanes' value must not be a
-    //    constant, or the cross-lane read of it is folded away);
-    //  * the atomic optimizer is switched off (Makefile, jit.cpp): it would wait for the
-    //    counter value right behind the atomic, and the point is to have it in flight while
-    //    the wave marches.
-    auto bump = [&](uint32_t counter) -> uint32_t {
-        uint32_t below;                              // lanes below this one: 0 in lane 0
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(below));
-        uint32_t v = below;
-        if (below == 0) v = __hip_atomic_fetch_add(kernarg_params()->set_cur + counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return v;
+    // One lane bumps a counter for the wave and the wave gets the old value.  Written as one asm
+    // block that narrows EXEC to lane 0 around the atomic: as C++ (`if (lane == 0) v = atomic...`
+    // followed by a cross-lane read) the compiler threads that branch through the queue's loops and
+    // splits the wave into a lane-0 path and a path of the other lanes, each with a queue state of
+    // its own - twice a hang on the device, in two different shapes of this code.  The block waits
+    // for the value itself (the compiler does not track memory operations inside an asm, so the
+    // result cannot be left in flight); the other wavefronts of the SIMD fill the microsecond, and
+    // cheap tiles take their places four at a time.
+    auto bump = [&](uint32_t counter, uint32_t by) -> uint32_t {
+        const uint32_t* base = kernarg_params()->set_cur;
+        uint32_t ret, off = counter * 4u, add = by;
+        unsigned long long save;
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "global_atomic_add %[ret], %[off], %[add], %[base] sc0\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "s_mov_b64 exec, %[save]"
+                     : [ret] "=&v"(ret), [save] "=&s"(save)
+                     : [off] "v"(off), [add] "v"(add), [base] "s"(base)
+                     : "memory");
+        return uniform(ret);
     };
 
     // stage A: the head being pulled from, and a counter value on its way
-    uint32_t a_cursor = 0, a_head = home, a_total = 0, a_ticket = 0;   // a_cursor: heads tried so far
+    // a_ticket: first place of the run of a_run places this wave holds in the head's sequence (one
+    // place among the costly tiles, which must spread over the waves; RM_QUEUE_CHUNK among the cheap
+    // ones at its end); a_pos: how many of them it has used
+    // Cheap tiles in runs, and in one unordered list, only in a launch of several frames, where the
+    // counters' throughput is what binds (measured on chair 4K: 0.335 -> 0.284 ms per frame at 8 frames
+    // per launch); a single frame is bound by how evenly its last tiles spread, and both cost it 0.1 ms.
+    const uint32_t pull_chunk = prm.nframes > 1 ? RM_QUEUE_CHUNK : 1;
+    uint32_t a_cursor = 0, a_head = home, a_total = 0, a_ticket = 0, a_run = 1, a_pos = 0;   // a_cursor: heads tried so far
     uint32_t a_cum[RM_COST_BUCKETS];                                   // running list lengths of a_head
     bool a_done = false;
     auto open_head = [&]() {
@@ -114,8 +127,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // walks all the heads, and atomics on one word go through L2 one at a time (~88 per us).
         // The counter only grows, so a stale value can only send a wave to the atomic needlessly.
         const uint32_t seen = uniform(__hip_atomic_load(kernarg_params()->set_cur + RM_SET_PULL(a_head), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        a_pos = 0;
+        a_run = seen >= a_cum[RM_CHEAP_BUCKET - 1] ? pull_chunk : 1;
         if (seen >= a_total) a_ticket = a_total;
-        else a_ticket = bump(RM_SET_PULL(a_head));
+        else a_ticket = bump(RM_SET_PULL(a_head), a_run);
     };
     // stage S: a tile id on its way (list entry), or already known (natural order)
     uint32_t s_val = 0;
@@ -123,7 +138,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     auto stage_s = [&]() {
         s_valid = false;
         while (!a_done) {
-            const uint32_t c = uniform(a_ticket);
+            const uint32_t c = uniform(a_ticket) + a_pos;
             if (c < a_total) {
                 if (ordered) {
                     uint32_t b = 0, base = 0;
@@ -137,7 +152,11 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     s_val = a_head + RM_QUEUE_HEADS * c;
                 }
                 s_valid = true;
-                a_ticket = bump(RM_SET_PULL(a_head));
+                if (++a_pos == a_run) {              // the run is used up: the next one is on its way while this tile marches
+                    a_pos = 0;
+                    a_run = c + 1 >= a_cum[RM_CHEAP_BUCKET - 1] ? pull_chunk : 1;
+                    a_ticket = bump(RM_SET_PULL(a_head), a_run);
+                }
                 return;
             }
             // this head is dry: on to the next one, the overflow list last (it exists only with history)
@@ -150,6 +169,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
 
     // optional per-wave diagnostics (rm_debug_wave_stats): trips, normal passes, cycles
     uint32_t st_evals = 0, st_norms = 0, st_norm_cycles = 0;
+    uint32_t r_base = 0, r_left = 0;         // places this wave holds in its head's cheap list (filing, below)
     const uint64_t st_t0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
 
     // Safety net for the persistent loop: every wave leaves after 2^36 shader cycles (about half
@@ -305,16 +325,34 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // ---- file the tile under its cost for the next frame
         KernargParams* fp = kernarg_params();
         if (fp->feedback) {
-            const uint32_t b = trips >= 384 ? 0 : trips >= 192 ? 1 : trips >= 96 ? 2 : trips >= 48 ? 3
-                             : trips >= 24 ? 4 : trips >= 12 ? 5 : trips >= 6 ? 6 : 7;
-            const uint32_t at = uniform(bump(RM_SET_COUNT(home, b)));
+            // a single frame keeps its cheap tiles in order too (three more buckets, a place at a time):
+            // its end is as even as the order of its last tiles
+            const uint32_t b = trips >= 384 ? 0 : trips >= 192 ? 1 : trips >= 96 ? 2 : trips >= 48 ? 3 : trips >= 24 ? 4
+                             : pull_chunk > 1 ? RM_CHEAP_BUCKET : trips >= 12 ? 5 : trips >= 6 ? 6 : 7;
+            uint32_t at;
+            if (b == RM_CHEAP_BUCKET && pull_chunk > 1) {   // places in the cheap list are taken RM_QUEUE_CHUNK at a time
+                if (r_left == 0) { r_base = uniform(bump(RM_SET_COUNT(home, RM_CHEAP_BUCKET), RM_QUEUE_CHUNK)); r_left = RM_QUEUE_CHUNK; }
+                at = r_base + (RM_QUEUE_CHUNK - r_left);
+                --r_left;
+            } else {
+                at = uniform(bump(RM_SET_COUNT(home, b), 1));
+            }
             if (at < fp->list_cap) {
                 fp->lists_cur[(size_t)(home * RM_COST_BUCKETS + b) * fp->list_cap + at] = tile_id;    // every lane, same word
             } else {                                 // list full: the overflow list takes any tile
-                const uint32_t at2 = uniform(bump(RM_SET_OVERFLOW));
+                const uint32_t at2 = uniform(bump(RM_SET_OVERFLOW, 1));
                 if (at2 < fp->overflow_cap)
                     fp->lists_cur[(size_t)RM_QUEUE_HEADS * RM_COST_BUCKETS * fp->list_cap + at2] = tile_id;
             }
+        }
+    }
+
+    // places taken in the cheap list and not filled: marked, so that the next launch skips them
+    if (!expired) {
+        KernargParams* fp = kernarg_params();
+        for (; r_left; --r_left) {
+            const uint32_t at = r_base + (RM_QUEUE_CHUNK - r_left);
+            if (at < fp->list_cap) fp->lists_cur[(size_t)(home * RM_COST_BUCKETS + RM_CHEAP_BUCKET) * fp->list_cap + at] = 0xffffffffu;
         }
     }
 

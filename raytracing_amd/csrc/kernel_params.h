@@ -19,6 +19,14 @@
 #define RM_SET_PULL(h)     ((h) * RM_QUEUE_STRIDE)
 #define RM_SET_COUNT(h, b) ((16 + 8 * (h) + (b)) * RM_QUEUE_STRIDE)
 #define RM_SET_OVERFLOW    (80 * RM_QUEUE_STRIDE)
+// Tiles of fewer than 24 loop trips are the bulk of most frames and too cheap to order among
+// themselves: they share cost bucket RM_CHEAP_BUCKET, and both ends of the queue handle them
+// RM_QUEUE_CHUNK at a time (one atomic per four tiles: a word takes ~88 atomics per microsecond, and a
+// 4K frame of cheap tiles is 130 k pulls and 130 k filings on 8 + 8 words).
+#define RM_CHEAP_BUCKET    5
+#ifndef RM_QUEUE_CHUNK
+#define RM_QUEUE_CHUNK     4
+#endif
 #define RM_SET_LINES       96
 #define RM_SET_DWORDS      (RM_SET_LINES * RM_QUEUE_STRIDE)
 

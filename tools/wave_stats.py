@@ -16,6 +16,8 @@ if os.environ.get("RM_JIT"): print("RM_JIT", os.environ["RM_JIT"])
 with api.Raymarching(w, h) as rm:
     rm.set_nodes(nodes)
     rm.set_info(O.default_info(1, 0))
+    for _ in range(int(os.environ.get("WARM_FRAMES", "0"))):      # let the tile order settle first
+        rm.process()
     ms = rm.process()
     st = rm.wave_stats().astype(np.float64)
 ev, nm, cyc, ncyc = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
