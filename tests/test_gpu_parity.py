@@ -314,6 +314,26 @@ def test_batch_of_frames_in_one_launch(stock_scenes):
                     rm.set_info_batch(infos)                 # three blocks for a batch of two
 
 
+def test_scene_every_ray_leaves_after_one_step():
+    """A unit sphere a million units away: every tile is one loop trip, so the launch is nothing but the
+    tile queue.  (With the queue's counter bump written in C++ this was the shape of code that hung the
+    device: the compiler split the wave into a lane-0 path and a rest-of-wave path.)  Several launches,
+    one frame and four frames per launch, against the oracle."""
+    table = scenes.Tree(("movo", (1e6, 0, 0), ("sfero", (1,)))).table()
+    info = O.default_info(1, 0)
+    w, h = 320, 200
+    ref = O.render(table, w, h, info, threads=min(16, os.cpu_count() or 4))
+    assert not ref["hit"].any()
+    for batch in (1, 4):
+        with api.Raymarching(w, h) as rm:
+            rm.set_nodes(table)
+            rm.set_batch(batch)
+            rm.set_info(info)
+            for launch in range(5):
+                rm.process()
+                assert np.array_equal(rm.read_pixels(), ref["rgba"]), (batch, launch)
+
+
 def test_external_output_and_pitch(stock_scenes):
     """rm_set_output: render into a caller-owned device buffer with a padded pitch."""
     torch = pytest.importorskip("torch")
