@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """perf_grid.py SCENE W H key=v1,v2 key=v1,v2 ...: kernel ms over the cross product of knob values.
-keys: refill, boost, heavy, norm_batch, jit"""
+keys: boost, heavy, evaluator, jit"""
 import itertools
 import os
 import sys
