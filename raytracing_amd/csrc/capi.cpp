@@ -544,14 +544,22 @@ int rm_process(rm_ctx* c, float* elapsed_ms) {
     return RM_OK;
 }
 
+// Device rows to host memory.  Rows that are contiguous on both sides go as one linear copy: into pageable
+// memory the runtime's 2-D path moves 1.9 GB/s on the GPU box, the linear one pipelines through its pinned staging.
+static int read_rows(rm_ctx* c, void* host, size_t host_pitch, const void* dev, size_t dev_pitch, size_t row_bytes) {
+    if (host_pitch == row_bytes && dev_pitch == row_bytes)
+        HIP_TRY(hipMemcpyAsync(host, dev, row_bytes * c->local_rows, hipMemcpyDeviceToHost, c->stream));
+    else
+        HIP_TRY(hipMemcpy2DAsync(host, host_pitch, dev, dev_pitch, row_bytes, c->local_rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
 int rm_read_pixels(rm_ctx* c, void* host_rgba, size_t pitch_bytes) {
     if (!c || !host_rgba || pitch_bytes < c->width * 4) return RM_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
     if (c->local_rows == 0) return RM_OK;
-    HIP_TRY(hipMemcpy2DAsync(host_rgba, pitch_bytes, c->out, c->out_pitch, c->width * 4, c->local_rows,
-                             hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return RM_OK;
+    return read_rows(c, host_rgba, pitch_bytes, c->out, c->out_pitch, c->width * 4);
 }
 
 int rm_read_hit_mask(rm_ctx* c, void* host_mask, size_t pitch_bytes) {
@@ -559,10 +567,7 @@ int rm_read_hit_mask(rm_ctx* c, void* host_mask, size_t pitch_bytes) {
     if (!c->hit) return RM_ERR_NOT_READY;
     HIP_TRY(hipSetDevice(c->device));
     if (c->local_rows == 0) return RM_OK;
-    HIP_TRY(hipMemcpy2DAsync(host_mask, pitch_bytes, c->hit, c->width, c->width, c->local_rows,
-                             hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return RM_OK;
+    return read_rows(c, host_mask, pitch_bytes, c->hit, c->width, c->width);
 }
 
 int rm_device_framebuffer(rm_ctx* c, void** device_rgba, size_t* pitch_bytes) {

@@ -353,6 +353,30 @@ def test_external_output_and_pitch(stock_scenes):
     assert not buf.cpu().numpy()[:, w * 4:].any(), "bytes beyond width*4 must stay untouched"
 
 
+def test_read_pixels_host_pitch(stock_scenes):
+    """rm_read_pixels / rm_read_hit_mask into a host frame with padded rows (the 2-D copy) and into a
+    contiguous one (the linear copy): same pixels, padding untouched."""
+    import ctypes as C
+    info = O.default_info(1, 0)
+    w, h = 100, 60
+    with api.Raymarching(w, h) as rm:
+        rm.set_nodes(stock_scenes["chair"])
+        rm.set_info(info)
+        rm.enable_hit_mask(True)
+        rm.process()
+        tight, tight_hit = rm.read_pixels(), rm.read_hit_mask()
+        wide = np.full((h, 512), 0xab, np.uint8)
+        api._check(api.lib().rm_read_pixels(rm._ctx, C.c_void_p(wide.ctypes.data), 512), "rm_read_pixels")
+        wide_hit = np.full((h, 128), 0xab, np.uint8)
+        api._check(api.lib().rm_read_hit_mask(rm._ctx, C.c_void_p(wide_hit.ctypes.data), 128), "rm_read_hit_mask")
+        assert api.lib().rm_read_pixels(rm._ctx, C.c_void_p(wide.ctypes.data), w * 4 - 1) == -1
+    ref = O.render(stock_scenes["chair"], w, h, info)
+    assert np.array_equal(tight, ref["rgba"])
+    assert np.array_equal(wide[:, : w * 4].reshape(h, w, 4), ref["rgba"]) and (wide[:, w * 4:] == 0xab).all()
+    assert np.array_equal(tight_hit, ref["hit"])
+    assert np.array_equal(wide_hit[:, :w], ref["hit"]) and (wide_hit[:, w:] == 0xab).all()
+
+
 def test_errors_are_reported(stock_scenes):
     with api.Raymarching(64, 64) as rm:
         with pytest.raises(api.RaymarchError) as e:
