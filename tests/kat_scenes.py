@@ -69,6 +69,67 @@ SCENES = {
 }
 
 
+def random_tree(seed, depth=5):
+    """A seeded random scene over all 20 node types: each level picks a combinator or a transform
+    with sane payloads (non-zero repeat vectors, unit rotations), leaves at the bottom.  For the
+    fuzz test: nestings nobody wrote down by hand."""
+    rng = np.random.default_rng(seed)
+
+    def f(lo, hi):
+        return float(np.float32(rng.uniform(lo, hi)))
+
+    def leaf():
+        kind = rng.integers(0, 10)
+        if kind < 3:
+            return ("sfero", (f(1, 5),))
+        if kind < 6:
+            return ("kubo", (f(1, 5), f(1, 5), f(1, 5)))
+        if kind < 9:
+            return ("cilindro", (f(1, 4), f(1, 5)))
+        n = np.array([f(-0.3, 0.3), f(-0.3, 0.3), 1.0], dtype=np.float32)
+        n = n / np.sqrt(np.sum(n * n), dtype=np.float32)
+        return ("movo", (0, 0, f(-9, -5)), ("ebeno", tuple(float(v) for v in n)))
+
+    def moved(t):
+        return ("movo", (f(-6, 6), f(-6, 6), f(-6, 6)), t)
+
+    def nudged(t):
+        return ("movo", (f(-2, 2), f(-2, 2), f(-2, 2)), t)
+
+    def big():
+        return ("sfero", (f(6, 10),)) if rng.random() < 0.5 else ("kubo", (f(5, 9), f(5, 9), f(5, 9)))
+
+    def build(d):
+        if d == 0 or (d < depth and rng.random() < 0.12):
+            return leaf()
+        pick = rng.integers(0, 16)
+        if pick < 3:
+            n = int(rng.integers(2, 5))
+            return ("kunigajo_%d" % n, ()) + tuple(moved(build(d - 1)) for _ in range(n))
+        if pick < 6:                              # a big solid first, so that the intersection is rarely empty
+            n = int(rng.integers(2, 5))
+            return ("komunajo_%d" % n, (), big()) + tuple(nudged(build(d - 1)) for _ in range(n - 1))
+        if pick == 6:
+            return ("komunajo_2", (), big(), ("komplemento", (), moved(build(d - 1))))
+        if pick == 7:
+            return ("glata_kunigajo_2", (f(0.3, 3),), build(d - 1), moved(build(d - 1)))
+        if pick == 8:
+            return ("glata_komunajo_2", (f(0.3, 3),), big(), nudged(build(d - 1)))
+        if pick == 9:
+            return moved(build(d - 1))
+        if pick in (10, 11, 12):
+            a = f(-3, 3)
+            return ("rotacio" + "XYZ"[pick - 10], (np.float32(np.cos(a)), np.float32(np.sin(a))), build(d - 1))
+        if pick == 13:
+            return ("rotacioQ", quaternion((f(-1, 1), f(-1, 1), f(0.1, 1)), f(-3, 3)), build(d - 1))
+        if pick == 14:
+            axis = [(f(12, 30), 0, 0), (0, f(12, 30), f(-3, 3)), (f(12, 30), f(-3, 3), f(-3, 3))][rng.integers(0, 3)]
+            return ("senfina_ripeto", axis, build(d - 1))
+        return ("portanta_sfero", (f(-2, 2), f(-2, 2), f(-2, 2), f(6, 14)), build(d - 1))
+
+    return ("kunigajo_3", (), moved(build(depth - 1)), moved(build(depth - 1)), moved(build(depth - 1)))
+
+
 def tables():
     return {name: Tree(t).table() for name, t in SCENES.items()}
 

@@ -97,6 +97,39 @@ def test_node_kat_inner_nodes():
             assert same_floats(n, O.norm_many(table, idx, pts)), idx
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RM_FUZZ_SEEDS", "24"))))
+def test_random_trees(seed):
+    """Fuzz: a seeded random tree over all 20 node types (kat_scenes.random_tree), DIST and NORM at seeded
+    points on every device evaluator and a small frame on the three kernels, against the oracle."""
+    table = scenes.Tree(kat_scenes.random_tree(1000 + seed, depth=3 + seed % 4)).table()
+    pts = kat_scenes.points(96, seed=seed)
+    want_d, want_n = O.dist_many(table, 0, pts), O.norm_many(table, 0, pts)
+    with api.Raymarching(64, 64) as rm:
+        rm.set_jit(2)
+        rm.set_nodes(table)
+        d_prog, _ = rm.eval_points(pts, 0, which=0, want_norm=False)
+        d_walk, n_walk = rm.eval_points(pts, 0, which=1, want_norm=True)
+        d_jit, n_jit = rm.eval_points(pts, 0, which=2, want_norm=True)
+        rm.set_jit(3)
+        rm.set_nodes(table)
+        d_jp, n_jp = rm.eval_points(pts, 0, which=2, want_norm=True)
+    for name, got, want in (("distance program DIST", d_prog, want_d), ("walker DIST", d_walk, want_d),
+                            ("walker NORM", n_walk, want_n), ("generated DIST", d_jit, want_d),
+                            ("generated NORM", n_jit, want_n), ("compiled program DIST", d_jp, want_d),
+                            ("compiled program NORM", n_jp, want_n)):
+        assert same_floats(got, want), "%s differs from the oracle (%d nodes)" % (name, len(table))
+    info = O.default_info(2, seed % 8)
+    info["StartPos"] = (-45.0, 2.0, 1.0)
+    for v in ("StartWVec", "StartHVec"):           # four times the default field of view: the whole scene in a small frame
+        for a in "xyz":
+            info[v][a] *= np.float32(4)
+    ref = O.render(table, 160, 96, info)
+    for path in ("jit", "jitprog", "program"):
+        rgba, hit, _ = gpu_render(table, 160, 96, info, path)
+        assert np.array_equal(hit, ref["hit"]), path
+        assert np.array_equal(rgba, ref["rgba"]), path
+
+
 def test_set_rays_kat():
     """kernel_SetRays (Source/cuda_kernels.cu:730-762) fused into the kernel."""
     for (w, h, phi) in [(640, 480, 0), (1920, 1080, 37), (7680, 4320, 119), (33, 17, 5)]:
