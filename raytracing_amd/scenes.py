@@ -110,8 +110,8 @@ class SplitMix64:
         return np.float32(np.float32(lo) + self.unit() * np.float32(hi - lo))
 
 
-def csg1024(seed=0x5CE1024):
-    """exactly 1024 records.
+def csg_union(seed, leaves, pad_to=None):
+    """SURVEY.md 8d config 4 (csg1024 = 341 leaves padded to exactly 1024 records), any size:
 
     record 0 = movo(t=(200,0,0)); a balanced binary kunigajo_2 tree (340 inner
     nodes) over 341 leaves, each leaf = movo(t in [-60,60]^3) -> one of
@@ -140,6 +140,11 @@ def csg1024(seed=0x5CE1024):
         b = union(count - left)
         return ("kunigajo_2", (), a, b)
 
-    table = Tree(("movo", (200, 0, 0), union(341))).table(pad_to=1024)
+    table = Tree(("movo", (200, 0, 0), union(leaves))).table(pad_to=pad_to)
+    return table
+
+
+def csg1024(seed=0x5CE1024):
+    table = csg_union(seed, 341, 1024)
     assert len(table) == 1024
     return table
