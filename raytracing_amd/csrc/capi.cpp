@@ -226,7 +226,8 @@ bool jit_source(const rm_node* nodes, size_t n, const rm::SceneBuild& built, con
         return true;
     }
     const size_t tree_bytes = built.tree.size() * sizeof(rm::TreeNode);
-    if (built.program.size() > rm::kJitMaxSlots || tree_bytes > rm::kJitMaxLds) return false;
+    // the tree table is only staged for the walker's normals; a union of primitives takes them from its own culled pass
+    if (built.program.size() > rm::kJitMaxSlots || (built.union_rank.empty() && tree_bytes > rm::kJitMaxLds)) return false;
     *src = rm::generate_program_source(built.program, built.value_slots, built.slot_node, built.union_rank);
     *lds_bytes = built.union_rank.empty() ? tree_bytes : 0;
     return true;
