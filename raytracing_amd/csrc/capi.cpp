@@ -548,11 +548,13 @@ int rm_process(rm_ctx* c, float* elapsed_ms) {
 // Device rows to host memory.  Rows that are contiguous on both sides go as one linear copy: into pageable
 // memory the runtime's 2-D path moves 1.9 GB/s on the GPU box, the linear one pipelines through its pinned staging.
 static int read_rows(rm_ctx* c, void* host, size_t host_pitch, const void* dev, size_t dev_pitch, size_t row_bytes) {
-    if (host_pitch == row_bytes && dev_pitch == row_bytes)
-        HIP_TRY(hipMemcpyAsync(host, dev, row_bytes * c->local_rows, hipMemcpyDeviceToHost, c->stream));
-    else
-        HIP_TRY(hipMemcpy2DAsync(host, host_pitch, dev, dev_pitch, row_bytes, c->local_rows, hipMemcpyDeviceToHost, c->stream));
+    // The frame is waited for first and the copy is the blocking kind: the destination may be pageable memory,
+    // and the call must not return before the last byte is in it.
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (host_pitch == row_bytes && dev_pitch == row_bytes)
+        HIP_TRY(hipMemcpy(host, dev, row_bytes * c->local_rows, hipMemcpyDeviceToHost));
+    else
+        HIP_TRY(hipMemcpy2D(host, host_pitch, dev, dev_pitch, row_bytes, c->local_rows, hipMemcpyDeviceToHost));
     return RM_OK;
 }
 
