@@ -97,8 +97,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // ones at its end); a_pos: how many of them it has used
     // Cheap tiles in runs, and in one unordered list, only in a launch of several frames, where the
     // counters' throughput is what binds (measured on chair 4K: 0.335 -> 0.284 ms per frame at 8 frames
-    // per launch); a single frame is bound by how evenly its last tiles spread, and both cost it 0.1 ms.
-    const uint32_t pull_chunk = prm.nframes > 1 ? RM_QUEUE_CHUNK : 1;
+    // per launch); a single frame is as long as its longest tile plus its share of the chip, and gains nothing
+    // from either (kernel_params.h RM_SINGLE_CHUNK).
+    const bool merged = prm.nframes > 1;
+    const uint32_t pull_chunk = merged ? RM_QUEUE_CHUNK : RM_SINGLE_CHUNK;
     uint32_t a_cursor = 0, a_head = home, a_total = 0, a_ticket = 0, a_run = 1, a_pos = 0;   // a_cursor: heads tried so far
     uint32_t a_cum[RM_COST_BUCKETS];                                   // running list lengths of a_head
     bool a_done = false;
@@ -328,9 +330,9 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             // a single frame keeps its cheap tiles in order too (three more buckets, a place at a time):
             // its end is as even as the order of its last tiles
             const uint32_t b = trips >= 384 ? 0 : trips >= 192 ? 1 : trips >= 96 ? 2 : trips >= 48 ? 3 : trips >= 24 ? 4
-                             : pull_chunk > 1 ? RM_CHEAP_BUCKET : trips >= 12 ? 5 : trips >= 6 ? 6 : 7;
+                             : merged ? RM_CHEAP_BUCKET : trips >= 12 ? 5 : trips >= 6 ? 6 : 7;
             uint32_t at;
-            if (b == RM_CHEAP_BUCKET && pull_chunk > 1) {   // places in the cheap list are taken RM_QUEUE_CHUNK at a time
+            if (b == RM_CHEAP_BUCKET && merged) {   // places in the cheap list are taken RM_QUEUE_CHUNK at a time
                 if (r_left == 0) { r_base = uniform(bump(RM_SET_COUNT(home, RM_CHEAP_BUCKET), RM_QUEUE_CHUNK)); r_left = RM_QUEUE_CHUNK; }
                 at = r_base + (RM_QUEUE_CHUNK - r_left);
                 --r_left;

@@ -27,6 +27,13 @@
 #ifndef RM_QUEUE_CHUNK
 #define RM_QUEUE_CHUNK     4
 #endif
+// A single frame's lists stay ordered down to the cheapest tiles and it pulls RM_SINGLE_CHUNK places at a
+// time: measured 1, 2, 4, 8 on the stock scenes (tools/single_frame_probe.py) - within noise of each other
+// (chair 4K 0.45-0.48 ms, 8K 1.48 -> 1.41), because such a launch is as long as its longest tile
+// (0.25 ms of dependent steps, about what a 1080p frame takes in all) plus its share of the chip.
+#ifndef RM_SINGLE_CHUNK
+#define RM_SINGLE_CHUNK    1
+#endif
 #define RM_SET_LINES       96
 #define RM_SET_DWORDS      (RM_SET_LINES * RM_QUEUE_STRIDE)
 
