@@ -79,6 +79,8 @@ def lib():
         L.rmo_render.restype = C.c_double
         L.rmo_default_info.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rmo_default_info.restype = None
+        L.rmo_camera_script.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.rmo_camera_script.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -120,6 +122,28 @@ def default_info(light_steps=1, phi_steps=0):
     info = np.zeros(1, dtype=INFO_DTYPE)
     lib().rmo_default_info(_ptr(info), light_steps, phi_steps)
     return info
+
+
+EVENTS = {"frame": 0, "left": 1, "right": 2, "space": 3, "pause": 4, "resume": 5, "wheel": 6, "pan": 7, "drag": 8}
+
+
+def camera_script(lines):
+    """The rays_info of every frame of a scripted run of the reference's event loop
+    (rmo_camera_script; main.cpp:144-270).  `lines`: the text of an rm_render --script file,
+    one event per line: frame | left | right | space | pause | resume | wheel N | pan DX DY | drag DX DY."""
+    ev = []
+    for ln in lines:
+        tok = ln.split("#")[0].split()
+        if not tok:
+            continue
+        args = [int(v) for v in tok[1:]] + [0, 0]
+        ev.append((EVENTS[tok[0]], args[0], args[1]))
+    ev = np.ascontiguousarray(ev, dtype=np.int32).reshape(-1, 3)
+    frames = sum(1 for e in ev if e[0] == 0)
+    out = np.zeros(max(frames, 1), dtype=INFO_DTYPE)
+    got = lib().rmo_camera_script(_ptr(ev), len(ev), _ptr(out), frames)
+    assert got == frames
+    return out[:frames]
 
 
 def dist(nodes, idx, p):

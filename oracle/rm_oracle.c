@@ -621,3 +621,81 @@ void rmo_default_info(rm_rays_info* info, int light_steps, int phi_steps) {
         info->LightSource = pt(cos_1 * L.x - sin_1 * L.y, sin_1 * L.x + cos_1 * L.y, L.z);
     }
 }
+
+/* Source/main.cpp:127-266 as a scripted event path: the state the reference's event loop keeps
+ * (scale, theta, phi, the pause flag) and what each SDL event does to it.  Events are int32
+ * triples (kind, a, b); RMO_EV_FRAME is one pass of the loop body after the events were polled:
+ * the light turns unless paused (:261-266) and the block that SetInfo would receive is emitted. */
+size_t rmo_camera_script(const int32_t* ev, size_t n_events, rm_rays_info* out, size_t cap) {
+    const float M_SQRT1_5f = .447213595499957939281f, half_pi = 1.57079632679489661923f;   /* M_PI_2f */
+    float scale = powf(2.f, -6.1f), theta = 0.f, cos_theta = 1.f, sin_theta = 0.f,
+          phi = 0.f, cos_phi = 1.f, sin_phi = 0.f;
+    float cos_1 = cosf(M_PI / 180.f), sin_1 = sinf(M_PI / 180.f), deg = M_PI / 360.f;
+    int pause = 0;
+    size_t frames = 0;
+    rm_rays_info I;
+    memset(&I, 0, sizeof I);
+    I.Depth = 1000;
+    I.LightSource = pt(-2.f * M_SQRT1_5f, 0.f, M_SQRT1_5f);
+    I.StartPos = pt(0.f, 0.f, 0.f);
+#define RMO_VECTORS() do { \
+        I.StartDir = pt(scale * cos_theta * cos_phi, scale * cos_theta * sin_phi, scale * sin_theta); \
+        I.StartWVec = pt(scale * sin_phi, -scale * cos_phi, 0.f); \
+        I.StartHVec = pt(scale * sin_theta * cos_phi, scale * sin_theta * sin_phi, -scale * cos_theta); } while (0)
+    RMO_VECTORS();
+    for (size_t k = 0; k < n_events; ++k) {
+        const int32_t kind = ev[3 * k], a = ev[3 * k + 1], b = ev[3 * k + 2];
+        rm_point L = I.LightSource;
+        switch (kind) {
+        case RMO_EV_FRAME:                                                            /* :261-270 */
+            if (!pause) I.LightSource = pt(cos_1 * L.x - sin_1 * L.y, sin_1 * L.x + cos_1 * L.y, L.z);
+            if (frames < cap) out[frames] = I;
+            ++frames;
+            break;
+        case RMO_EV_LEFT:                                                             /* :158-164 */
+            I.LightSource = pt(cos_1 * L.x - sin_1 * L.y, sin_1 * L.x + cos_1 * L.y, L.z);
+            break;
+        case RMO_EV_RIGHT:                                                            /* :165-171 */
+            I.LightSource = pt(cos_1 * L.x + sin_1 * L.y, -sin_1 * L.x + cos_1 * L.y, L.z);
+            break;
+        case RMO_EV_SPACE:                                                            /* :172-186 */
+            scale = powf(2.f, -2.1f);
+            theta = 0.f; cos_theta = 1.f; sin_theta = 0.f;
+            phi = 0.f; cos_phi = 1.f; sin_phi = 0.f;
+            I.StartPos = pt(0.f, 0.f, 0.f);
+            RMO_VECTORS();
+            break;
+        case RMO_EV_PAUSE:  pause = 1; break;                                         /* :187-188 */
+        case RMO_EV_RESUME: pause = 0; break;                                         /* :195-196 */
+        case RMO_EV_WHEEL:                                                            /* :219-226 */
+            scale *= powf(2.f, (float)a * .1f);
+            RMO_VECTORS();
+            break;
+        case RMO_EV_PAN: {                                                            /* :231-238 */
+            float S = 2.f / scale;
+            I.StartPos.x -= (float)a * I.StartWVec.x * S;
+            I.StartPos.y -= (float)a * I.StartWVec.y * S;
+            I.StartPos.z -= (float)a * I.StartWVec.z * S;
+            I.StartPos.x -= (float)b * I.StartHVec.x * S;
+            I.StartPos.y -= (float)b * I.StartHVec.y * S;
+            I.StartPos.z -= (float)b * I.StartHVec.z * S;
+            RMO_VECTORS();                                                            /* :253-255 */
+            break;
+        }
+        case RMO_EV_DRAG:                                                             /* :239-255 */
+            theta += (float)b * deg;
+            if (theta > half_pi) theta = half_pi;
+            else if (theta < -half_pi) theta = -half_pi;
+            cos_theta = cosf(theta);
+            sin_theta = sinf(theta);
+            phi += (float)a * deg;
+            cos_phi = cosf(phi);
+            sin_phi = sinf(phi);
+            RMO_VECTORS();
+            break;
+        default: break;
+        }
+    }
+#undef RMO_VECTORS
+    return frames;
+}

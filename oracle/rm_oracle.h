@@ -95,6 +95,23 @@ double rmo_render(const rm_node* nodes, size_t n, size_t width, size_t height,
  * (main.cpp:248-255). */
 void rmo_default_info(rm_rays_info* info, int light_steps, int phi_steps);
 
+/* The reference's event loop (main.cpp:144-270) driven by a script: `ev` holds
+ * n_events int32 triples (kind, a, b).  Every RMO_EV_FRAME emits the rays_info
+ * the loop would hand to SetInfo for that frame; returns the number of frames
+ * (at most `cap` are stored). */
+enum {
+    RMO_EV_FRAME = 0,   /* end of the polling loop: light turns unless paused, render   */
+    RMO_EV_LEFT = 1,    /* SDLK_LEFT: light +1 degree                                   */
+    RMO_EV_RIGHT = 2,   /* SDLK_RIGHT: light -1 degree                                  */
+    RMO_EV_SPACE = 3,   /* SDLK_SPACE: camera reset (scale 2^-2.1)                      */
+    RMO_EV_PAUSE = 4,   /* 'p' down                                                     */
+    RMO_EV_RESUME = 5,  /* 'p' up                                                       */
+    RMO_EV_WHEEL = 6,   /* a = wheel.y                                                  */
+    RMO_EV_PAN = 7,     /* mouse motion (a, b) pixels, middle button down               */
+    RMO_EV_DRAG = 8     /* mouse motion (a, b) pixels, right button down                */
+};
+size_t rmo_camera_script(const int32_t* ev, size_t n_events, rm_rays_info* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

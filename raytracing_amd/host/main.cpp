@@ -3,7 +3,13 @@
 // call sequence (Source/main.cpp:67-138, 261-270, 292-293), with a PPM dump in
 // the place of the SDL window.
 //
-//   rm_render --width W --height H [--input scene.sce] [--frames K] [--drag-x PX] [--drag-y PX] [--out frame.ppm] [--device D]
+//   rm_render --width W --height H [--input scene.sce] [--frames K] [--drag-x PX] [--drag-y PX] [--script events.txt]
+//             [--out frame.ppm] [--device D]
+//
+// --script: the reference's event loop (Source/main.cpp:144-270) driven from a file, one event per line:
+//   frame | left | right | space | pause | resume | wheel N | pan DX DY | drag DX DY
+// (SDLK_LEFT/RIGHT/SPACE/p, the mouse wheel, mouse motion with the middle or the right button down);
+// every `frame` line is one pass of the loop body: the light turns unless paused, SetInfo, Process.
 //
 // Without --input the scene hard-coded in Source/main.cpp:86-123 is built with
 // the same create_from calls.  Without --width/--height the reference takes the
@@ -15,7 +21,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <string>
 
 #include "rays.hpp"
@@ -44,7 +52,7 @@ int main(int argc, char** argv) {
     size_t Width = 0, Height = 0, Frames = 1;
     int DragX = 0, DragY = 0;          // scripted right-button drag per frame, pixels (Source/main.cpp:240-251)
     int Device = 0;
-    string File, Out;
+    string File, Out, Script;
 
     string arg;
     bitset<3> correctInit;
@@ -59,6 +67,7 @@ int main(int argc, char** argv) {
         else if (arg == "drag-x")  { DragX = atoi(argv[++I]); }
         else if (arg == "drag-y")  { DragY = atoi(argv[++I]); }
         else if (arg == "out")     { Out = argv[++I]; }
+        else if (arg == "script")  { Script = argv[++I]; }
         else if (arg == "device")  { Device = atoi(argv[++I]); }
     }
     if (!correctInit[0]) Width = 1920;
@@ -113,6 +122,87 @@ int main(int argc, char** argv) {
 
     double kernel_ms = 0.0;
     auto t0 = chrono::steady_clock::now();
+    auto set_vectors = [&]() {                                   // Source/main.cpp:253-255
+        Info_h.StartDir = point{ scale * cos_theta * cos_phi, scale * cos_theta * sin_phi, scale * sin_theta };
+        Info_h.StartWVec = point{ scale * sin_phi, -scale * cos_phi, 0.f };
+        Info_h.StartHVec = point{ scale * sin_theta * cos_phi, scale * sin_theta * sin_phi, -scale * cos_theta };
+    };
+    if (!Script.empty()) {
+        ifstream in(Script);
+        if (!in) { cerr << "cannot read " << Script << endl; return 1; }
+        bool pause = false;
+        Frames = 0;
+        string line;
+        while (getline(in, line)) {
+            line = line.substr(0, line.find('#'));
+            istringstream tok(line);
+            string what;
+            int a = 0, b = 0;
+            if (!(tok >> what)) continue;
+            tok >> a >> b;
+            if (what == "left") {                                 // Source/main.cpp:158-164
+                Info_h.LightSource = point{
+                    cos_1 * Info_h.LightSource.x - sin_1 * Info_h.LightSource.y,
+                    sin_1 * Info_h.LightSource.x + cos_1 * Info_h.LightSource.y,
+                    Info_h.LightSource.z };
+            } else if (what == "right") {                         // :165-171
+                Info_h.LightSource = point{
+                    cos_1 * Info_h.LightSource.x + sin_1 * Info_h.LightSource.y,
+                    -sin_1 * Info_h.LightSource.x + cos_1 * Info_h.LightSource.y,
+                    Info_h.LightSource.z };
+            } else if (what == "space") {                         // :172-186
+                scale = powf(2.f, -2.1f);
+                theta = 0.f; cos_theta = 1.f; sin_theta = 0.f;
+                phi = 0.f; cos_phi = 1.f; sin_phi = 0.f;
+                Info_h.StartPos = point{ 0.f, 0.f, 0.f };
+                set_vectors();
+            } else if (what == "pause") {                         // :187-188
+                pause = true;
+            } else if (what == "resume") {                        // :195-196
+                pause = false;
+            } else if (what == "wheel") {                         // :219-226
+                scale *= powf(2.f, float(a) * .1f);
+                set_vectors();
+            } else if (what == "pan") {                           // :231-238
+                float S = 2.f / scale;
+                Info_h.StartPos.x -= float(a) * Info_h.StartWVec.x * S;
+                Info_h.StartPos.y -= float(a) * Info_h.StartWVec.y * S;
+                Info_h.StartPos.z -= float(a) * Info_h.StartWVec.z * S;
+                Info_h.StartPos.x -= float(b) * Info_h.StartHVec.x * S;
+                Info_h.StartPos.y -= float(b) * Info_h.StartHVec.y * S;
+                Info_h.StartPos.z -= float(b) * Info_h.StartHVec.z * S;
+                set_vectors();
+            } else if (what == "drag") {                          // :239-255
+                theta += float(b) * deg;
+                if (theta > M_PI_2f) theta = M_PI_2f;
+                else if (theta < -M_PI_2f) theta = -M_PI_2f;
+                cos_theta = cosf(theta);
+                sin_theta = sinf(theta);
+                phi += float(a) * deg;
+                cos_phi = cosf(phi);
+                sin_phi = sinf(phi);
+                set_vectors();
+            } else if (what == "frame") {                         // :261-270
+                if (!pause)
+                    Info_h.LightSource = point{
+                        cos_1 * Info_h.LightSource.x - sin_1 * Info_h.LightSource.y,
+                        sin_1 * Info_h.LightSource.x + cos_1 * Info_h.LightSource.y,
+                        Info_h.LightSource.z };
+                HIP->SetInfo(Info_h);
+                HIP->Process();
+                if (backend->LastStatus()) {
+                    cerr << "Process failed: " << backend->LastStatus() << " (" << rm_status_string(backend->LastStatus()) << ")" << endl;
+                    return 1;
+                }
+                kernel_ms += backend->ProcessTime();
+                ++Frames;
+            } else {
+                cerr << Script << ": unknown event '" << what << "'" << endl;
+                return 1;
+            }
+        }
+        if (Frames == 0) { cerr << Script << ": no frame line" << endl; return 1; }
+    } else
     for (size_t frame = 0; frame < Frames; ++frame) {
         auto f0 = chrono::steady_clock::now();
         // Source/main.cpp:240-255, scripted: from the second frame on the mouse has moved (DragX, DragY)

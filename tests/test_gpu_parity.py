@@ -595,6 +595,30 @@ def test_front_end_scripted_sweep(stock_scenes, golden_dir, tmp_path):
         assert f.read() == O.ppm_bytes(ref["rgba"])
 
 
+def test_front_end_event_script(stock_scenes, golden_dir, tmp_path):
+    """rm_render --script: every event of the reference's loop (Source/main.cpp:148-266: light keys, reset,
+    pause, wheel, middle-button pan, right-button drag) from a file; the front end's own float maths must
+    land on the oracle's camera block for the last frame, and the PPM on the oracle's frame for it."""
+    import subprocess
+    script = ["frame", "wheel 2", "drag 14 -9", "frame", "pan 30 -12", "left", "left", "frame", "pause", "right",
+              "frame", "space", "wheel -38", "drag -25 6", "pan -8 3", "resume", "frame  # the one that is written"]
+    path = tmp_path / "events.txt"
+    path.write_text("\n".join(script) + "\n")
+    out = str(tmp_path / "script.ppm")
+    w, h = 320, 180
+    run = subprocess.run([os.path.join(ROOT, "raytracing_amd", "rm_render"), "--width", str(w), "--height", str(h), "--input",
+                          os.path.join(golden_dir, "scenes", "chair.sce"), "--script", str(path), "--out", out],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr + run.stdout
+    assert "5 frame(s)" in run.stdout
+    infos = O.camera_script(script)
+    assert len(infos) == 5
+    ref = O.render(stock_scenes["chair"], w, h, infos[4:5], threads=min(16, os.cpu_count() or 4))
+    assert ref["hit"].sum() > 1000                                # the script ends looking at the scene
+    with open(out, "rb") as f:
+        assert f.read() == O.ppm_bytes(ref["rgba"])
+
+
 def test_bench_two_ranks_on_one_gpu(golden_dir):
     """bench.py's N>1 path end to end, two ranks sharing this GPU (RM_BENCH_REHEARSAL: gloo gather
     through host copies instead of RCCL): launches of several frames, luminance planes gathered,

@@ -89,6 +89,35 @@ def test_sweep_fixture(golden_dir):
     assert sweep[0]["StartDir"]["y"] == 0 and sweep[0]["StartHVec"]["z"] == -sweep[0]["StartDir"]["x"]
 
 
+def test_camera_script(golden_dir):
+    """rmo_camera_script (the reference's event loop, main.cpp:144-270, as a scripted path): a right-drag of
+    one pixel per frame is the committed sweep; every other event against the closed forms of its lines."""
+    sweep = np.fromfile(os.path.join(golden_dir, "sweep_rays_info.bin"), dtype=O.INFO_DTYPE)
+    lines = ["frame"] + ["drag 1 0", "frame"] * 119
+    assert O.camera_script(lines).tobytes() == sweep.tobytes()
+    f32 = np.float32
+    base = O.default_info(0, 0)[0]
+    # pause holds the light, left and right undo each other only up to rounding, resume lets it turn again
+    got = O.camera_script(["pause", "frame", "left", "frame", "resume", "frame"])
+    assert got[0]["LightSource"] == base["LightSource"]
+    assert got[1]["LightSource"] == O.default_info(1, 0)[0]["LightSource"]
+    assert got[2]["LightSource"] == O.default_info(2, 0)[0]["LightSource"]
+    # wheel: scale *= 2^(0.1 y) (:220); space: scale = 2^-2.1 and everything else back (:173-184)
+    got = O.camera_script(["wheel 3", "pan 5 -2", "frame", "space", "frame"])
+    def pow2(e):                                                  # powf(2.f, e): the double result, rounded once
+        return f32(2.0 ** float(f32(e)))
+    scale = f32(pow2(-6.1) * pow2(f32(3) * f32(0.1)))
+    assert got[0]["StartDir"]["x"] == scale and got[0]["StartWVec"]["y"] == -scale
+    S = f32(f32(2.0) / scale)                                     # :232-238, WVec = (0,-scale,0), HVec = (0,0,-scale)
+    assert got[0]["StartPos"]["y"] == f32(f32(0) - f32(f32(f32(5) * -scale) * S))
+    assert got[0]["StartPos"]["z"] == f32(f32(0) - f32(f32(f32(-2) * -scale) * S))
+    assert got[1]["StartDir"]["x"] == pow2(-2.1) and got[1]["StartPos"]["y"] == 0 and got[1]["StartPos"]["z"] == 0
+    # theta is clamped to +-pi/2 (:241-244)
+    got = O.camera_script(["drag 0 400", "frame", "drag 0 -900", "frame"])
+    assert got[0]["StartDir"]["z"] == pow2(-6.1)                  # scale * sinf(pi/2)
+    assert got[1]["StartDir"]["z"] == -got[0]["StartDir"]["z"]
+
+
 def test_sce_codec_round_trip(stock_scenes, golden_dir):
     """Appendix B: decode the stock files, re-encode, decode again."""
     for name, nodes in stock_scenes.items():
