@@ -34,6 +34,15 @@
 #ifndef RM_SINGLE_CHUNK
 #define RM_SINGLE_CHUNK    1
 #endif
+#ifndef RM_PRIO_TIERS        // 1: a long tile's priority rises in three steps; 0: straight to the top at boost_age
+#define RM_PRIO_TIERS      1
+#endif
+#ifndef RM_PRIO_STEP2
+#define RM_PRIO_STEP2      3
+#endif
+#ifndef RM_PRIO_STEP3
+#define RM_PRIO_STEP3      6
+#endif
 #define RM_SET_LINES       96
 #define RM_SET_DWORDS      (RM_SET_LINES * RM_QUEUE_STRIDE)
 

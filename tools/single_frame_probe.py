@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""single_frame_probe.py: median and minimum kernel time of one frame per launch, stock scenes at three
-sizes; run under different RM_JIT_FLAGS (e.g. -DRM_SINGLE_CHUNK=1) to compare builds (GPU box)."""
+"""single_frame_probe.py: median and minimum kernel time per frame, one frame per launch and eight, stock
+scenes at three sizes and csg1024; run under different RM_JIT_FLAGS (e.g. -DRM_SINGLE_CHUNK=1) to compare builds (GPU box)."""
 import os
 import sys
 
@@ -10,12 +10,16 @@ from oracle import oracle as O          # camera block only
 from raytracing_amd import api
 
 print("RM_JIT_FLAGS =", os.environ.get("RM_JIT_FLAGS", ""))
-for scene, w, h in (("chair", 3840, 2160), ("chair", 1920, 1080), ("chair", 7680, 4320), ("infinity", 3840, 2160)):
-    nodes = api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
-    with api.Raymarching(w, h) as rm:
-        rm.set_nodes(nodes)
-        rm.set_info(O.default_info(1, 0))
-        for _ in range(8):
-            rm.process()
-        t = sorted(rm.process() for _ in range(41))
-        print("  %-8s %dx%d  median %.4f ms  min %.4f ms" % (scene, w, h, t[20], t[0]), flush=True)
+from raytracing_amd import scenes
+for scene, w, h in (("chair", 3840, 2160), ("chair", 1920, 1080), ("chair", 7680, 4320), ("infinity", 3840, 2160), ("csg1024", 3840, 2160)):
+    nodes = scenes.csg1024() if scene == "csg1024" else api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
+    reps = 9 if scene == "csg1024" else 41
+    for batch in (1, 8):
+        with api.Raymarching(w, h) as rm:
+            rm.set_nodes(nodes)
+            rm.set_batch(batch)
+            rm.set_info(O.default_info(1, 0))
+            for _ in range(4 if scene == "csg1024" else 8):
+                rm.process()
+            t = sorted(rm.process() / batch for _ in range(reps))
+            print("  %-8s %dx%d  %d per launch: median %.4f ms  min %.4f ms per frame" % (scene, w, h, batch, t[reps // 2], t[0]), flush=True)

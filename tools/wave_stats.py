@@ -11,10 +11,15 @@ from oracle import oracle as O          # camera block only
 from raytracing_amd import api
 
 scene, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-nodes = api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
+if scene == "csg1024":
+    from raytracing_amd import scenes
+    nodes = scenes.csg1024()
+else:
+    nodes = api.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
 if os.environ.get("RM_JIT"): print("RM_JIT", os.environ["RM_JIT"])
 with api.Raymarching(w, h) as rm:
     rm.set_nodes(nodes)
+    rm.set_batch(int(os.environ.get("BATCH", "1")))
     rm.set_info(O.default_info(1, 0))
     for _ in range(int(os.environ.get("WARM_FRAMES", "0"))):      # let the tile order settle first
         rm.process()
