@@ -71,7 +71,10 @@ def measured_traffic(workload):
     cannot run inside the timed region): {"bytes": ..., "source": ...} or None."""
     try:
         import glob
-        with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))[-1]) as f:      # the latest build profiled
+        import re
+        names = glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json"))
+        latest = max(names, key=lambda p: [int(v) for v in re.findall(r"\d+", os.path.basename(p))])     # r01_v10 after r01_v9
+        with open(latest) as f:                                                                          # the latest build profiled
             rec = json.load(f)
         if rec.get("workload") == workload:
             return {"bytes": rec["hbm_bytes_per_launch"], "source": rec["source"]}
