@@ -34,8 +34,8 @@
 #ifndef RM_SINGLE_CHUNK
 #define RM_SINGLE_CHUNK    1
 #endif
-#ifndef RM_PRIO_TIERS        // 1: a long tile's priority rises in three steps; 0: straight to the top at boost_age
-#define RM_PRIO_TIERS      1
+#ifndef RM_PRIO_LEVELS       // how far a long tile's priority rises (1..3), a step at a time (device_render.h)
+#define RM_PRIO_LEVELS     3
 #endif
 #ifndef RM_PRIO_STEP2
 #define RM_PRIO_STEP2      3
