@@ -207,16 +207,15 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         make_ray(cam, width, height, (int)px, (int)gy, pos, rd);
         float t = 0.f, cd = 0.f, n_l = 0.f, shadow = 1.f;
         int mode = in_image ? M_PRIMARY : M_DONE, steps = 0;
-        uint32_t pixel = 0xff000000u, hit = 0;   // Source/cuda_kernels.cu:622
+        // what a shaded lane carries out of the loop: its luminance byte L (:694) under a flag bit; the pixel
+        // is a function of L alone and is put together once, after the loop (one loop-carried value, not two)
+        uint32_t shaded = 0;
         uint32_t trips = 0;                      // loop trips of this tile: its cost
         // A tile that runs long goes ahead of the others on its SIMD, a step at a time (s_setprio 1, 2, 3
         // after boost_age, RM_PRIO_STEP2 x and RM_PRIO_STEP3 x boost_age trips): the longest tiles set the
-        // length of a frame, and where several long ones share a SIMD the longest should win.  Measured
-        // against every long tile straight at priority 3 (tools/prio_probe.py): chair 4K 0.289 -> 0.276 ms
-        // per frame, infinity 0.895 -> 0.835.  Part of that is not scheduling: under the 78 scalar registers
-        // of the 8-wave build this form of the check also happens to leave the march loop with selects on
-        // VCC instead of on scalar pairs, 14 vector moves fewer per trip (chair); a one-level variant that
-        // does the same thing at run time compiles to the longer loop and measures like the old one.
+        // length of a frame, and where several long ones share a SIMD the longest should win.  Measured in
+        // four interleaved sweeps (tools/prio_probe.py) against one step and against every long tile
+        // straight at priority 3: chair 4K 0.286 / 0.284 -> 0.276 ms per frame, infinity 0.894 / 0.875 -> 0.821.
         uint32_t level = 0;
         const uint32_t boost_age = tp->boost_age;
         const bool boost_on = boost_age < (1u << 24);
@@ -232,9 +231,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         };
         auto finish = [&]() {                                                      // :693-701
             float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
-            float L = (float)to_u8(lum);
-            pixel = to_u8(L * RM_MATERIAL_R) | (to_u8(L * RM_MATERIAL_G) << 8) | (to_u8(L * RM_MATERIAL_B) << 16) | 0xff000000u;
-            hit = 1;
+            shaded = 0x100u | to_u8(lum);
             mode = M_DONE;
         };
         auto shadow_tail = [&]() {                                                 // :679-690
@@ -331,6 +328,12 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         if (expired) break;
 
         if (in_image) {                                                            // :717
+            const uint32_t hit = shaded >> 8;
+            uint32_t pixel = 0xff000000u;                                          // :622
+            if (hit) {                                                             // :695-699
+                const float L = (float)(shaded & 0xffu);
+                pixel = to_u8(L * RM_MATERIAL_R) | (to_u8(L * RM_MATERIAL_G) << 8) | (to_u8(L * RM_MATERIAL_B) << 16) | 0xff000000u;
+            }
             KernargParams* ep = kernarg_params();
             *reinterpret_cast<uint32_t*>(ep->rgba + frame * ep->frame_stride + (size_t)ly * ep->pitch + (size_t)px * 4) = pixel;
             if (ep->hit) ep->hit[frame * ep->hit_frame_stride + (size_t)ly * ep->hit_pitch + (size_t)px] = (uint8_t)hit;
