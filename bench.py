@@ -66,39 +66,66 @@ def golden_frame(scene, w, h):
         return json.load(f).get("%s_%dx%d" % (scene, w, h))
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch from the last committed counter profile of this workload (rocprofv3 --pmc
-    cannot run inside the timed region): {"bytes": ..., "source": ...} or None."""
-    try:
-        import glob
-        import re
-        names = glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json"))
-        latest = max(names, key=lambda p: [int(v) for v in re.findall(r"\d+", os.path.basename(p))])     # r01_v10 after r01_v9
-        with open(latest) as f:                                                                          # the latest build profiled
-            rec = json.load(f)
-        if rec.get("workload") == workload:
-            return {"bytes": rec["hbm_bytes_per_launch"], "source": rec["source"]}
-    except (OSError, ValueError, KeyError):
-        pass
+def measured_traffic(workload, frames_per_launch):
+    """HBM bytes per launch from the latest committed counter profile of THIS workload (rocprofv3 --pmc
+    cannot run inside the timed region): {"bytes": ..., "source": ...} or None.  A profile taken at
+    another number of frames per launch is scaled to this run's."""
+    import glob
+    import re
+    names = glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json"))
+    for path in sorted(names, key=lambda p: [int(v) for v in re.findall(r"\d+", os.path.basename(p))], reverse=True):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            if rec.get("workload") != workload:
+                continue
+            per = rec.get("frames_per_launch", 8)
+            return {"bytes": rec["hbm_bytes_per_launch"] * frames_per_launch / per, "source": rec["source"]}
+        except (OSError, ValueError, KeyError):
+            continue
     return None
+
+
+def host_cpu():
+    """What the CPU baseline ran on: the model name, the machine's logical CPUs, and how many this
+    process may use (the GPU box gives a one-GPU job a share of the machine)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, allowed
 
 
 def cpu_baseline(scene, w, h, info, want):
     """The CPU restatement (oracle/) timed on this box's host cores, one full frame."""
     from oracle import oracle as O
     nodes = O.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", scene + ".sce"))
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # every core this job may use: the GPU box hands a one-GPU job 16 threads of the machine and says so in
+    # OMP_NUM_THREADS (its nproc shows the whole machine); elsewhere, the cores the process may run on
+    model, nproc, allowed = host_cpu()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or allowed
+    host = {"cpu_model": model, "nproc": nproc, "cpus_allowed": allowed,
+            "threads_from": "OMP_NUM_THREADS" if os.environ.get("OMP_NUM_THREADS") else "sched_getaffinity"}
     if scene == "csg1024":          # a full 4K frame of this scene is ~an hour of CPU: sample rows
         rows = (h // 2 - 2, h // 2 + 2)
         t0 = time.perf_counter()
         O.render(nodes, w, h, info, rows=rows)
         secs = time.perf_counter() - t0
         return {"value": w * (rows[1] - rows[0]) / secs / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-                "sample": "rows %d-%d of the %dx%d frame, 1 thread" % (rows[0], rows[1] - 1, w, h)}
+                "sample": "rows %d-%d of the %dx%d frame, 1 thread" % (rows[0], rows[1] - 1, w, h), **host}
     r = O.render(nodes, w, h, info, threads=threads, want_counters=True)
     out = {"value": w * h / r["seconds"] / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
            "sample": "1 full %dx%d frame of %s.sce, rows dealt over %d threads" % (w, h, scene, threads),
-           "seconds": r["seconds"], "flops": r["counters"]["flops"], "hits": r["counters"]["hits"]}
+           "seconds": r["seconds"], "flops": r["counters"]["flops"], "hits": r["counters"]["hits"], **host}
     # one thread, on a band of 32 rows through the middle of the image (SURVEY.md 8d asks for both)
     rows = (h // 2 - 16, h // 2 + 16)
     t0 = time.perf_counter()
@@ -122,7 +149,9 @@ def main():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the extra frame-per-launch measurement (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=0, help="contexts taking launches in turn (0 = 1 for N=1, 3 for N>1)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="frames whose tiles one launch pools (rm_set_batch), 1..8; 0 = 8")
+                    help="frames whose tiles one launch pools (rm_set_batch), 1..32; 0 = 8")
+    ap.add_argument("--warmup-seconds", type=float, default=0.25,
+                    help="warm up for at least this long as well as for --warmup frames (clocks, tile order)")
     args = ap.parse_args()
 
     # N>1: four contexts render a rank's shares of consecutive frames at once, each on its own stream,
@@ -134,7 +163,6 @@ def main():
     import torch
     import torch.distributed as dist
     from raytracing_amd import api, tiling
-    from oracle import oracle as O      # camera block + cpu_baseline only; never in the timed path
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -161,10 +189,11 @@ def main():
 
     scene, w, h = WORKLOADS[args.workload]
     nodes = load_nodes(scene)
-    info = O.default_info(1, 0)          # main.cpp default camera, light at +1 degree ("frame 0")
-    sweep = None
-    if args.workload.endswith("_sweep"):
-        sweep = np.fromfile(os.path.join(ROOT, "tests", "golden", "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
+    # main.cpp's default camera with the light at +1 degree ("frame 0") is block 0 of the committed sweep
+    # (tests/test_oracle.py checks that it is); the other blocks are config 5's camera path
+    blocks = np.fromfile(os.path.join(ROOT, "tests", "golden", "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
+    info = blocks[0:1].copy()
+    sweep = blocks if args.workload.endswith("_sweep") else None
     want = None if sweep is not None else golden_frame(scene, w, h)
     in_flight = args.in_flight or (1 if world == 1 else 3)
 
@@ -188,7 +217,7 @@ def main():
     # its longest ray marches (tools/slice_rate.py: 5.2 k shares/s per GPU one at a time, 18-22 k/s
     # with 8 per launch).  `single_frame_launch` in the output is the frame-at-a-time figure.
     batch = args.frames_per_launch or 8
-    batch = max(1, min(8, batch))
+    batch = max(1, min(32, batch))
     if world > 1:
         # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
         # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), the frames of a launch
@@ -215,28 +244,17 @@ def main():
             rm.set_output(f.data_ptr(), w * 4)
         frame = None                                   # the last frame rendered: set by launch()
         strides = (h * w * 4, 0)
-    cur_batch = [1] * in_flight
-    state = {"ctx": 0, "pending": [], "launches": 0, "last": None}
-
-    def launch():
-        """The pending frames as one launch of the current context (then, N>1, their gather to rank 0)."""
-        j, infos = state["ctx"], state["pending"]
-        n = len(infos)
-        if n == 0:
-            return
-        rm = ctxs[j]
+    for rm in ctxs:                                    # room for `batch` frames per launch, once, before anything is timed
+        rm.set_batch(batch, *strides)
+    def before_launch(j):
         if world > 1:
             streams[j].wait_event(gathered[j])         # context j's slab is free again
-        if cur_batch[j] != n:                          # the first launch, and a last one that is not full
-            rm.set_batch(n, *strides)
-            cur_batch[j] = n
-        rm.set_info_batch(np.concatenate(infos))
-        rm.process_async()
-        state["launches"] += 1
-        state["last"] = (j, n - 1)
-        state["ctx"], state["pending"] = (j + 1) % in_flight, []
+
+    def after_launch(j, n):
+        """N>1: the launch's luminance planes to rank 0 in one gather, RGBA8 frames rebuilt there."""
         if world == 1:
             return
+        rm = ctxs[j]
         rendered[j].record(streams[j])
         comm_stream.wait_event(rendered[j])
         with torch.cuda.stream(comm_stream):           # same order of gathers on every rank
@@ -255,48 +273,64 @@ def main():
                                           frame.data_ptr(), w * 4, stream=comm_stream.cuda_stream)
             gathered[j].record(comm_stream)
 
+    from raytracing_amd.batching import FrameBatcher
+    run = FrameBatcher(ctxs, batch, before=before_launch, after=after_launch)
+
     def step(k):
-        state["pending"].append(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
-        if len(state["pending"]) == batch:
-            launch()
+        run.step(info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1])
 
     def drain():
-        launch()                                       # frames that do not fill a launch
-        for st in streams:
-            st.synchronize()
+        run.flush()                                    # frames that do not fill a launch
+        for rm in ctxs:
+            rm.synchronize()                           # also the completeness check: raises on a frame with tiles missing
         if world > 1:
             comm_stream.synchronize()
         torch.cuda.synchronize()
 
-    # warm-up: whole launches only (a launch that is not full would reset the tile order the
-    # contexts have learnt), so a few frames more than asked when --warmup is no multiple
+    # Warm-up: at least --warmup frames, in whole launches, and at least --warmup-seconds of them: a fresh
+    # box needs a few hundred milliseconds of work before its clocks are where a long run has them, and the
+    # tile order is learnt from the launch before.  Every rank runs the same number of launches (the
+    # gathers are collective), so the ranks agree on the count.
     warm = -(-args.warmup // batch) * batch
+    t_warm = time.perf_counter()
     for k in range(warm):
         step(k)
     drain()
+    while True:
+        more = 1 if time.perf_counter() - t_warm < args.warmup_seconds else 0
+        if world > 1:
+            flag = torch.tensor([more], dtype=torch.int32, device="cpu" if rehearsal else dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = int(flag.item())
+        if not more:
+            break
+        for k in range(4 * batch * in_flight):
+            step(warm + k)
+        warm += 4 * batch * in_flight
+        drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    state["launches"] = 0
+    run.launches = 0
     t0 = time.perf_counter()
-    ev0.record(streams[state["ctx"]])
+    ev0.record(streams[run.ctx])
     for k in range(args.steps):
         step(warm + k)
-    launch()                                           # exactly --steps frames: the last launch may hold fewer
-    ev1.record(streams[state["last"][0]])
+    run.flush()                                        # exactly --steps frames: the last launch may hold fewer
+    ev1.record(streams[run.last[0]])
     drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
-    launches = max(1, state["launches"])
+    launches = max(1, run.launches)
     # One context: the kernel's average duration (launch to launch on its stream).  With several
     # in flight kernels overlap; the region's time per launch is what counts then.
     kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / launches
     if world == 1:
-        frame = frames[state["last"][0]][state["last"][1]]
+        frame = frames[run.last[0]][run.last[1]]
 
     if world > 1:
         tmax = torch.tensor([secs], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -312,7 +346,7 @@ def main():
         out = {
             "metric": "Mrays/s at 3840x2160 on chair.sce" if args.workload == "chair_4k" else "Mrays/s (%s)" % args.workload,
             "value": mrays, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_frames_run": warm,
             "ms_per_step": secs * 1e3 / args.steps,
             "frames_per_s": args.steps / secs,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, **({"rehearsal": True} if rehearsal else {}),
@@ -330,7 +364,7 @@ def main():
         if want:
             flops = want["counters"]["flops"] / world * args.steps / launches      # per launch: 1/N of each of its frames
             achieved = flops / (kernel_ms * 1e-3) / 1e12
-            traffic = measured_traffic(args.workload) if world == 1 else None
+            traffic = measured_traffic(args.workload, args.steps / launches) if world == 1 else None
             out["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                                "traffic": traffic["bytes"] if traffic else None,

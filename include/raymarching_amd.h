@@ -10,7 +10,12 @@
  *
  * Conventions (Source/cuda_rays.cu:3-5): every call returns 0 on success.  A
  * positive value is a hipError_t, a negative value one of enum rm_status.
- * Unlike the reference, an error is never latched and silently carried on.
+ * Unlike the reference, an error is never latched and silently carried on:
+ * every call that waits for the device (rm_process, rm_synchronize, rm_read_*)
+ * also checks that every tile of every frame launched since the last check was
+ * rendered, and returns RM_ERR_INCOMPLETE otherwise (the kernel is a set of
+ * persistent wavefronts pulling tiles from a queue; a wavefront that its watchdog
+ * stopped, or a tile that went missing, must not pass for a finished frame).
  * All calls are synchronous on the context's stream unless stated otherwise.
  * A context is not thread-safe; use one per host thread / per GPU.
  *
@@ -39,7 +44,8 @@ enum rm_status {
     RM_ERR_NOT_READY   = -6,  /* rm_process before primitives and info were set      */
     RM_ERR_NO_KERNEL   = -7,  /* the HIP code object for gfx950 could not be loaded  */
     RM_ERR_JIT         = -8,  /* run-time compilation of the scene failed            */
-    RM_ERR_ARITHMETIC  = -9   /* the device's short sqrt sequence is not IEEE sqrtf  */
+    RM_ERR_ARITHMETIC  = -9,  /* the device's short sqrt sequence is not IEEE sqrtf  */
+    RM_ERR_INCOMPLETE  = -10  /* a launched frame did not render all its tiles       */
 };
 
 #define RM_MAX_NODES 2048     /* reference: 256 (Source/cuda_kernels.cu:607) */
@@ -95,17 +101,21 @@ int rm_set_nodes(rm_ctx* ctx, const rm_node* nodes, size_t n);
 int rm_set_info(rm_ctx* ctx, const rm_rays_info* info);
 
 /* Several frames per launch (no counterpart: the reference renders one frame per
- * Process()).  After rm_set_batch(ctx, n, ...) every rm_process / rm_process_async
- * renders n frames (1..RM_MAX_BATCH) in ONE kernel launch: the tiles of all n frames
- * form one pool for the persistent wavefronts, so the long tiles of one frame run
- * beside the short ones of the others.  A rank's share of a frame on 8 GPUs is too
- * little work to fill the chip for as long as its longest ray takes; a batch is.
- * Frame f uses the f-th camera block of rm_set_info_batch (rm_set_info gives all
- * frames the same block) and writes its planes `*_frame_stride_bytes` after frame
- * f-1's: RGBA8 output, luminance plane; 0 = packed (pitch x rows of this context).
- * With the context's own framebuffer rm_read_pixels returns frame 0.  Changing the
- * batch forgets the tile order learnt from earlier frames.  Synchronises the stream. */
-#define RM_MAX_BATCH 8
+ * Process()).  rm_set_batch(ctx, n, ...) makes room for launches of up to n frames
+ * (1..RM_MAX_BATCH): every rm_process / rm_process_async then renders its frames in
+ * ONE kernel launch, the tiles of all of them in one pool for the persistent
+ * wavefronts, so the long tiles of one frame run beside the short ones of the
+ * others.  A rank's share of a frame on 8 GPUs is too little work to fill the chip
+ * for as long as its longest ray takes; a batch is.
+ * How many frames the next launch holds is set with the cameras: rm_set_info gives
+ * all n frames the same block; rm_set_info_batch(ctx, infos, m) gives frame f the
+ * f-th block and makes the launch m <= n frames long (a last launch that is not
+ * full costs no reallocation, no wait and keeps the tile order learnt so far).
+ * Frame f writes its planes `*_frame_stride_bytes` after frame f-1's: RGBA8 output,
+ * luminance plane; 0 = packed (pitch x rows of this context).  With the context's
+ * own framebuffer rm_read_pixels returns frame 0.  rm_set_batch waits for the
+ * stream; it allocates only when n grows beyond anything set before. */
+#define RM_MAX_BATCH 32
 int rm_set_batch(rm_ctx* ctx, size_t frames, size_t rgba_frame_stride_bytes, size_t luminance_frame_stride_bytes);
 int rm_set_info_batch(rm_ctx* ctx, const rm_rays_info* infos, size_t n);
 
@@ -136,7 +146,7 @@ int rm_assemble_luminance(rm_ctx* ctx, const void* device_parts, size_t rank_str
                           void* device_rgba, size_t pitch_bytes, void* hip_stream);
 
 /* Optional explicit hit mask: one byte per
- * pixel, 1 where the pixel was shaded.  enable != 0 allocates it. */
+ * pixel, 1 where the pixel was shaded.  enable != 0 allocates it, zeroed. */
 int rm_enable_hit_mask(rm_ctx* ctx, int enable);
 
 /* Process (Include/rays.h:35; Source/cuda_rays.cu:201-216): render one frame
@@ -240,6 +250,13 @@ int rm_set_evaluator(rm_ctx* ctx, int which);
  * dwords: march loop trips, normal passes, shader cycles in the kernel, cycles
  * in normal passes.  With host_out NULL only *n_waves is set. */
 int rm_debug_wave_stats(rm_ctx* ctx, uint32_t* host_out, size_t cap_waves, size_t* n_waves);
+
+/* Diagnostics: the persistent wavefronts' watchdog, in s_memtime ticks (0 restores
+ * the default, 2^36).  A wavefront that has been in the kernel for longer gives up
+ * at its next look at the clock (every 1024 march-loop trips, and where a tile's
+ * priority steps up: rm_set_boost_age) and the launch is reported as
+ * RM_ERR_INCOMPLETE.  Tests lower it to see that error path work. */
+int rm_debug_set_watchdog(rm_ctx* ctx, unsigned long long ticks);
 
 const char* rm_status_string(int status);
 

@@ -30,6 +30,7 @@ EXPORTS = [
     "rm_flatten_scene", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
     "rm_set_luminance_output", "rm_assemble_luminance", "rm_set_batch", "rm_set_info_batch",
+    "rm_debug_set_watchdog",
 ]
 
 
@@ -96,6 +97,7 @@ def lib():
             "rm_flatten_scene": [vp, sz, C.POINTER(SceneStats), C.c_char_p, sz],
             "rm_set_evaluator": [vp, i32],
             "rm_set_boost_age": [vp, C.c_uint],
+            "rm_debug_set_watchdog": [vp, C.c_ulonglong],
             "rm_set_heavy_first": [vp, i32],
             "rm_selftest_math": [vp, vp, sz, C.POINTER(C.c_ulonglong), vp],
             "rm_set_short_math": [vp, i32],
@@ -271,6 +273,9 @@ class Raymarching:
 
     def set_boost_age(self, trips):
         _check(lib().rm_set_boost_age(self._ctx, trips), "rm_set_boost_age")
+
+    def set_watchdog(self, ticks):
+        _check(lib().rm_debug_set_watchdog(self._ctx, ticks), "rm_debug_set_watchdog")
 
     def set_evaluator(self, which):
         _check(lib().rm_set_evaluator(self._ctx, which), "rm_set_evaluator")

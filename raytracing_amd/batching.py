@@ -1,0 +1,42 @@
+"""Frames of a sequence handed to contexts in launches of several frames (rm_set_batch).
+
+bench.py's render loop, kept apart from it so that the order of C-ABI calls a run makes can be
+checked without a GPU: a launch takes its frame count from rm_set_info_batch, so a last launch that
+is not full calls nothing that allocates, waits or forgets the tile order (rm_set_batch is called
+once per context, before anything is timed).
+"""
+import numpy as np
+
+
+class FrameBatcher:
+    """step(info) collects camera blocks; every `batch` of them (and flush(), for what is left) becomes
+    one launch of the next context in turn: before(j) -> set_info_batch -> process_async -> after(j, n)."""
+
+    def __init__(self, ctxs, batch, before=None, after=None):
+        self.ctxs, self.batch = list(ctxs), int(batch)
+        self.before, self.after = before, after
+        self.ctx = 0                  # the context the next launch goes to
+        self.pending = []
+        self.launches = 0
+        self.last = None              # (context index, slot of the last frame in its launch)
+
+    def step(self, info):
+        self.pending.append(info)
+        if len(self.pending) == self.batch:
+            self.flush()
+
+    def flush(self):
+        n = len(self.pending)
+        if n == 0:
+            return
+        j = self.ctx
+        if self.before:
+            self.before(j)
+        rm = self.ctxs[j]
+        rm.set_info_batch(np.concatenate(self.pending))      # n <= batch cameras: this launch renders n frames
+        rm.process_async()
+        self.launches += 1
+        self.last = (j, n - 1)
+        self.ctx, self.pending = (j + 1) % len(self.ctxs), []
+        if self.after:
+            self.after(j, n)

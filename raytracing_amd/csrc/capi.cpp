@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <set>
@@ -39,7 +40,8 @@ struct rm_ctx {
     uint32_t n_nodes = 0;
     bool have_scene = false, have_info = false;
     rm::Camera cams[RM_MAX_BATCH];    // cams[f]: camera of frame f of a launch
-    size_t batch = 1;                 // frames per launch (rm_set_batch)
+    size_t batch = 1;                 // frames a launch may hold (rm_set_batch): what the planes and lists are sized for
+    size_t nframes = 1;               // frames the next launch renders (rm_set_info: batch; rm_set_info_batch(n): n)
     size_t out_frame_stride = 0, lum_frame_stride = 0;   // 0: planes packed (pitch x local rows)
     size_t fb_bytes = 0, hit_bytes = 0;
 
@@ -48,15 +50,21 @@ struct rm_ctx {
     uint32_t evaluator = 0;
     size_t lds_bytes = 0;
 
-    // tile scheduler (device_render.h): three counter sets and three groups of tile lists used by
-    // frames seq, seq+1, seq+2 in turn.  A frame zeroes the next frame's set itself, so no memset
-    // sits between frames.
-    uint32_t* sched = nullptr;        // [3 sets][3 x ([8 heads][8 buckets][list_cap] + [overflow_cap])]
-    uint32_t seq = 0;                 // frame sequence number
+    // tile scheduler (device_render.h): three counter sets used by launches seq, seq+1, seq+2 in turn
+    // (a launch zeroes the next one's set itself, so no memset sits between launches) and two groups of
+    // tile lists (the one the previous launch wrote, the one this launch writes).
+    uint32_t* sched = nullptr;        // [3 sets][2 x ([8 heads][8 buckets][list_cap] + [overflow_cap])][status]
+    uint32_t seq = 0;                 // launch sequence number
     uint32_t list_cap = 0, overflow_cap = 0;
-    bool feedback = true;             // frames file their tiles by cost for the next frame
-    bool history = false;             // the previous frame did, with the same tile numbering
+    bool feedback = true;             // launches file their tiles by cost for the next launch
+    bool history = false;             // the previous launch did, with the same tile numbering...
+    size_t history_frames = 0;        // ...for this many frames: a launch of more frames starts in natural order
+    // completion accounting (kernel_params.h, RM_STATUS_*): tiles launched so far against tiles the
+    // wavefronts report finished, both modulo 2^32
+    uint32_t* status_host = nullptr;  // pinned copy of the device's status block
+    uint32_t expected_done = 0;
     uint32_t boost_age = 48;
+    unsigned long long watchdog = 1ull << 36;
     bool cull = true;                 // bounding-sphere tests in union chains (scene_build.cpp)
     bool short_math = true;           // scenes may use div_const for divisors the device has proved
     uint32_t exact_divisors = 0;      // how many of the current scene's divisor constants were
@@ -85,8 +93,20 @@ int sqrt_sweep(rm_ctx* c, uint32_t first, unsigned long long count, unsigned lon
     return static_cast<int>(e);
 }
 
-size_t list_group_dwords(const rm_ctx* c) {
-    return static_cast<size_t>(RM_QUEUE_HEADS) * RM_COST_BUCKETS * c->list_cap + c->overflow_cap;
+size_t list_group_dwords(uint32_t list_cap, uint32_t overflow_cap) {
+    return static_cast<size_t>(RM_QUEUE_HEADS) * RM_COST_BUCKETS * list_cap + overflow_cap;
+}
+size_t list_group_dwords(const rm_ctx* c) { return list_group_dwords(c->list_cap, c->overflow_cap); }
+
+// dwords of one scheduler block: three counter sets, two list groups, the status block
+size_t sched_dwords(uint32_t list_cap, uint32_t overflow_cap) {
+    return 3 * RM_SET_DWORDS + 2 * list_group_dwords(list_cap, overflow_cap) + RM_STATUS_DWORDS;
+}
+// list capacities for `tiles` tiles per launch: a head sees about an eighth of the tiles, so a quarter
+// per list leaves room for imbalance; what does not fit goes to the overflow list, which holds every tile
+void list_caps(size_t tiles, uint32_t* list_cap, uint32_t* overflow_cap) {
+    *overflow_cap = static_cast<uint32_t>(tiles);
+    *list_cap = static_cast<uint32_t>(tiles / 4 + 16);
 }
 
 size_t count_local_rows(size_t height, size_t band_rows, int rank, int nranks) {
@@ -96,6 +116,21 @@ size_t count_local_rows(size_t height, size_t band_rows, int rank, int nranks) {
         if (static_cast<int>(b % static_cast<size_t>(nranks)) == rank)
             rows += (height - y < band_rows) ? height - y : band_rows;
     return rows;
+}
+
+// where launch `seq` finds its counter sets, list groups and status block inside a scheduler block
+void point_at_schedule(rm::RenderParams& p, uint32_t* sched, uint32_t seq, uint32_t list_cap, uint32_t overflow_cap) {
+    const uint32_t cur = seq % 3, prev = (seq + 2) % 3, next = (seq + 1) % 3;
+    const size_t group = list_group_dwords(list_cap, overflow_cap);
+    uint32_t* lists = sched + 3 * RM_SET_DWORDS;
+    p.set_cur = sched + cur * RM_SET_DWORDS;
+    p.set_prev = sched + prev * RM_SET_DWORDS;
+    p.set_next = sched + next * RM_SET_DWORDS;
+    p.lists_cur = lists + (seq & 1u) * group;
+    p.lists_prev = lists + ((seq + 1) & 1u) * group;
+    p.list_cap = list_cap;
+    p.overflow_cap = overflow_cap;
+    p.status = lists + 2 * group;
 }
 
 void fill_params(const rm_ctx* c, rm::RenderParams& p) {
@@ -113,28 +148,22 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;
     p.lum = c->lum;  p.lum_pitch = c->lum_pitch;
-    p.nframes = static_cast<uint32_t>(c->batch);
+    p.nframes = static_cast<uint32_t>(c->nframes);
     p.frame_stride = c->out_frame_stride ? c->out_frame_stride : c->out_pitch * c->local_rows;
     p.hit_frame_stride = c->width * c->local_rows;
     p.lum_frame_stride = c->lum_frame_stride ? c->lum_frame_stride : c->lum_pitch * c->local_rows;
     for (size_t f = 0; f < RM_MAX_BATCH; ++f) p.cams[f] = c->cams[f];
     p.boost_age = c->boost_age;
-    const uint32_t cur = c->seq % 3, prev = (c->seq + 2) % 3, next = (c->seq + 1) % 3;
-    uint32_t* lists = c->sched + 3 * RM_SET_DWORDS;
-    p.set_cur = c->sched + cur * RM_SET_DWORDS;
-    p.set_prev = c->sched + prev * RM_SET_DWORDS;
-    p.set_next = c->sched + next * RM_SET_DWORDS;
-    p.lists_cur = lists + cur * list_group_dwords(c);
-    p.lists_prev = lists + prev * list_group_dwords(c);
-    p.list_cap = c->list_cap;
-    p.overflow_cap = c->overflow_cap;
+    p.watchdog = c->watchdog;
+    point_at_schedule(p, c->sched, c->seq, c->list_cap, c->overflow_cap);
     p.feedback = c->feedback ? 1u : 0u;
-    p.ordered = (c->feedback && c->history) ? 1u : 0u;
+    // the lists of the previous launch hold the tiles of its frames: a launch of fewer frames skips the
+    // entries beyond its own, a launch of more frames would miss tiles
+    p.ordered = (c->feedback && c->history && c->nframes <= c->history_frames) ? 1u : 0u;
 }
 
-size_t sched_bytes(const rm_ctx* c) {
-    return (3 * RM_SET_DWORDS + 3 * list_group_dwords(c)) * sizeof(uint32_t);
-}
+size_t sched_bytes(const rm_ctx* c) { return sched_dwords(c->list_cap, c->overflow_cap) * sizeof(uint32_t); }
+uint32_t* status_block(const rm_ctx* c) { return c->sched + 3 * RM_SET_DWORDS + 2 * list_group_dwords(c); }
 
 // forget the previous frame's tile lists (the tile numbering changed, or feedback was switched)
 hipError_t reset_schedule(rm_ctx* c) {
@@ -143,8 +172,10 @@ hipError_t reset_schedule(rm_ctx* c) {
 }
 
 // persistent grid: what the chip holds at once, or fewer when the image has few tiles
-unsigned render_blocks(const rm_ctx* c, bool jit) {
-    const size_t tiles = ((c->width + 7) / 8) * ((c->local_rows + 7) / 8) * c->batch;
+size_t local_tiles(const rm_ctx* c) { return ((c->width + 7) / 8) * ((c->local_rows + 7) / 8); }
+
+unsigned render_blocks(const rm_ctx* c, bool jit, size_t frames) {
+    const size_t tiles = local_tiles(c) * frames;
     // Four wavefronts per workgroup, and enough tiles per wavefront that starting it and having it
     // find every queue head dry at the end is small beside its work: a share of a frame (row bands
     // on 8 ranks) must not launch a wavefront per two tiles, and a smaller grid leaves room for the
@@ -166,12 +197,34 @@ int launch_frame(rm_ctx* c, uint32_t* wave_stats, size_t* waves) {
     fill_params(c, p);
     p.wave_stats = wave_stats;
     const bool jit = c->jit_active && c->evaluator == 0;
-    const unsigned blocks = render_blocks(c, jit);
+    const unsigned blocks = render_blocks(c, jit, c->nframes);
     if (waves) *waves = static_cast<size_t>(blocks) * 4;
     hipError_t e = jit ? rm::jit_launch_render(c->jit, p, blocks, c->stream)
                        : rm::launch_render(p, blocks, c->lds_bytes, c->stream);
-    if (e == hipSuccess) { ++c->seq; c->history = c->feedback; }
+    if (e == hipSuccess) {
+        ++c->seq; c->history = c->feedback; c->history_frames = c->nframes;
+        c->expected_done += static_cast<uint32_t>(local_tiles(c) * c->nframes);
+    }
     return static_cast<int>(e);
+}
+
+// Completion check, after a wait on the context's stream that followed `fetch_status`: every tile
+// launched so far must have been reported finished and no wavefront may have left on the watchdog.
+// Otherwise some frame since the last check is incomplete: the caller is told, and the next launch
+// starts from a clean schedule in natural order (a lost tile is in no list).
+hipError_t fetch_status(rm_ctx* c) {
+    return hipMemcpyAsync(c->status_host, status_block(c), RM_STATUS_DWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+}
+int judge_status(rm_ctx* c) {
+    uint32_t done = 0;
+    for (int k = 0; k < RM_STATUS_COUNTERS; ++k) done += c->status_host[k * RM_STATUS_STRIDE];
+    if (done == c->expected_done && c->status_host[RM_STATUS_FLAG] == 0) return RM_OK;
+    c->expected_done = done;
+    c->history = false;
+    (void)hipMemsetAsync(c->sched, 0, 3 * RM_SET_DWORDS * sizeof(uint32_t), c->stream);
+    (void)hipMemsetAsync(status_block(c) + RM_STATUS_FLAG, 0, sizeof(uint32_t), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    return RM_ERR_INCOMPLETE;
 }
 
 // Runs `count` numerators from bit pattern `first` through div_const for every divisor;
@@ -287,6 +340,20 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     return RM_OK;
 }
 
+// the context's own framebuffer, grown (never shrunk) to hold `frames` frames; the stream must be idle
+int grow_framebuffer(rm_ctx* c, size_t frames) {
+    const size_t need = c->width * c->height * 4 * frames;
+    if (need <= c->fb_bytes) return RM_OK;
+    uint8_t* fb = nullptr;
+    HIP_TRY(hipMalloc(&fb, need));
+    hipError_t e = hipMemset(fb, 0, need);
+    if (e != hipSuccess) { (void)hipFree(fb); return static_cast<int>(e); }
+    if (c->out == c->fb) c->out = fb;
+    (void)hipFree(c->fb);
+    c->fb = fb; c->fb_bytes = need;
+    return RM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -321,12 +388,11 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     c->fb_bytes = width * height * 4;
     if (e == hipSuccess) e = hipMalloc(&c->fb, c->fb_bytes);
-    // a head sees about an eighth of the tiles: a quarter per list leaves room for imbalance,
-    // and what does not fit goes to the overflow list, which can hold every tile
-    c->overflow_cap = static_cast<uint32_t>(((width + 7) / 8) * ((height + 7) / 8));
-    c->list_cap = c->overflow_cap / 4 + 16;
+    if (e == hipSuccess) e = hipMemset(c->fb, 0, c->fb_bytes);
+    list_caps(((width + 7) / 8) * ((height + 7) / 8), &c->list_cap, &c->overflow_cap);
     if (e == hipSuccess) e = hipMalloc(&c->sched, sched_bytes(c));
     if (e == hipSuccess) e = hipMemset(c->sched, 0, sched_bytes(c));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->status_host), RM_STATUS_DWORDS * sizeof(uint32_t), hipHostMallocDefault);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) e = rm::kernel_attributes(&c->vgprs, &c->scratch);
     if (e != hipSuccess) { rm_destroy(c); return e == hipErrorInvalidDeviceFunction ? RM_ERR_NO_KERNEL : static_cast<int>(e); }
@@ -358,6 +424,7 @@ int rm_destroy(rm_ctx* c) {
     if (c->fb) (void)hipFree(c->fb);
     if (c->hit) (void)hipFree(c->hit);
     if (c->sched) (void)hipFree(c->sched);
+    if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -373,7 +440,14 @@ int rm_set_stream(rm_ctx* c, void* hip_stream) {
 
 int rm_set_output(rm_ctx* c, void* device_rgba, size_t pitch_bytes) {
     if (!c) return RM_ERR_INVALID_ARG;
-    if (!device_rgba) { c->out = c->fb; c->out_pitch = c->width * 4; return RM_OK; }
+    if (!device_rgba) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        int rc = grow_framebuffer(c, c->batch);          // room for every frame of a launch (rm_set_batch)
+        if (rc != RM_OK) return rc;
+        c->out = c->fb; c->out_pitch = c->width * 4;
+        return RM_OK;
+    }
     if (pitch_bytes < c->width * 4 || (pitch_bytes & 3) || (reinterpret_cast<uintptr_t>(device_rgba) & 3))
         return RM_ERR_INVALID_ARG;
     c->out = static_cast<uint8_t*>(device_rgba); c->out_pitch = pitch_bytes;
@@ -433,6 +507,7 @@ int rm_set_info(rm_ctx* c, const rm_rays_info* info) {
     if (!c || !info) return RM_ERR_INVALID_ARG;
     camera_from(info, c->cams[0]);
     for (size_t f = 1; f < RM_MAX_BATCH; ++f) c->cams[f] = c->cams[0];      // every frame of a batch, until told otherwise
+    c->nframes = c->batch;
     c->have_info = true;
     return RM_OK;
 }
@@ -441,6 +516,7 @@ int rm_set_info_batch(rm_ctx* c, const rm_rays_info* infos, size_t n) {
     if (!c || !infos || n == 0 || n > c->batch) return RM_ERR_INVALID_ARG;
     for (size_t f = 0; f < n; ++f) camera_from(infos + f, c->cams[f]);
     for (size_t f = n; f < RM_MAX_BATCH; ++f) c->cams[f] = c->cams[n - 1];
+    c->nframes = n;            // a launch that is not full: no reallocation, and the tile order learnt so far stays
     c->have_info = true;
     return RM_OK;
 }
@@ -451,40 +527,37 @@ int rm_set_batch(rm_ctx* c, size_t frames, size_t rgba_frame_stride_bytes, size_
     if (tiles * frames > (size_t(1) << 30)) return RM_ERR_INVALID_ARG;       // tile ids are 32-bit
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    // the scheduler's lists hold a launch's tiles; the context's own planes hold all its frames
-    if (frames != c->batch) {
-        const uint32_t overflow = static_cast<uint32_t>(tiles * frames);
-        const uint32_t list_cap = overflow / 4 + 16;
-        const size_t bytes = (3 * RM_SET_DWORDS + 3 * (static_cast<size_t>(RM_QUEUE_HEADS) * RM_COST_BUCKETS * list_cap + overflow)) *
-                             sizeof(uint32_t);
+    // The scheduler's lists hold a launch's tiles and the context's own planes hold all its frames: both
+    // only ever grow, so going back to fewer frames (or launching fewer with rm_set_info_batch) allocates
+    // nothing and keeps the tile order learnt so far.
+    uint32_t list_cap = 0, overflow_cap = 0;
+    list_caps(tiles * frames, &list_cap, &overflow_cap);
+    if (sched_dwords(list_cap, overflow_cap) > sched_dwords(c->list_cap, c->overflow_cap)) {
+        const size_t bytes = sched_dwords(list_cap, overflow_cap) * sizeof(uint32_t);
         uint32_t* sched = nullptr;
         HIP_TRY(hipMalloc(&sched, bytes));
         hipError_t e = hipMemset(sched, 0, bytes);
         if (e != hipSuccess) { (void)hipFree(sched); return static_cast<int>(e); }
         (void)hipFree(c->sched);
-        c->sched = sched; c->overflow_cap = overflow; c->list_cap = list_cap;
-    } else {
-        HIP_TRY(hipMemset(c->sched, 0, 3 * RM_SET_DWORDS * sizeof(uint32_t)));
+        c->sched = sched; c->overflow_cap = overflow_cap; c->list_cap = list_cap;
+        c->history = false; c->seq = 0; c->expected_done = 0;
     }
-    const size_t fb_need = c->width * c->height * 4 * frames;
-    if (fb_need > c->fb_bytes) {
-        uint8_t* fb = nullptr;
-        HIP_TRY(hipMalloc(&fb, fb_need));
-        if (c->out == c->fb) c->out = fb;
-        (void)hipFree(c->fb);
-        c->fb = fb; c->fb_bytes = fb_need;
+    if (c->out == c->fb) {               // a caller-owned output needs no planes of the context's own
+        int rc = grow_framebuffer(c, frames);
+        if (rc != RM_OK) return rc;
     }
     if (c->hit && c->width * c->height * frames > c->hit_bytes) {
         uint8_t* hit = nullptr;
         HIP_TRY(hipMalloc(&hit, c->width * c->height * frames));
+        hipError_t e = hipMemset(hit, 0, c->width * c->height * frames);
+        if (e != hipSuccess) { (void)hipFree(hit); return static_cast<int>(e); }
         (void)hipFree(c->hit);
         c->hit = hit; c->hit_bytes = c->width * c->height * frames;
     }
     c->batch = frames;
+    c->nframes = frames;
     c->out_frame_stride = rgba_frame_stride_bytes;
     c->lum_frame_stride = luminance_frame_stride_bytes;
-    c->history = false;
-    c->seq = 0;
     return RM_OK;
 }
 
@@ -510,7 +583,11 @@ int rm_local_rows(rm_ctx* c, size_t* rows) {
 int rm_enable_hit_mask(rm_ctx* c, int enable) {
     if (!c) return RM_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    if (enable && !c->hit) { c->hit_bytes = c->width * c->height * c->batch; HIP_TRY(hipMalloc(&c->hit, c->hit_bytes)); }
+    if (enable && !c->hit) {
+        c->hit_bytes = c->width * c->height * c->batch;
+        HIP_TRY(hipMalloc(&c->hit, c->hit_bytes));
+        HIP_TRY(hipMemset(c->hit, 0, c->hit_bytes));       // a pixel no tile wrote reads as a miss, not as what the memory held
+    }
     if (!enable && c->hit) { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipFree(c->hit); c->hit = nullptr; }
     return RM_OK;
 }
@@ -529,8 +606,9 @@ int rm_process_async(rm_ctx* c) {
 int rm_synchronize(rm_ctx* c) {
     if (!c) return RM_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(fetch_status(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return RM_OK;
+    return judge_status(c);
 }
 
 int rm_process(rm_ctx* c, float* elapsed_ms) {
@@ -540,9 +618,10 @@ int rm_process(rm_ctx* c, float* elapsed_ms) {
     int rc = rm_process_async(c);
     if (rc != RM_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(fetch_status(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
-    return RM_OK;
+    return judge_status(c);
 }
 
 // Device rows to host memory.  Rows that are contiguous on both sides go as one linear copy: into pageable
@@ -550,7 +629,10 @@ int rm_process(rm_ctx* c, float* elapsed_ms) {
 static int read_rows(rm_ctx* c, void* host, size_t host_pitch, const void* dev, size_t dev_pitch, size_t row_bytes) {
     // The frame is waited for first and the copy is the blocking kind: the destination may be pageable memory,
     // and the call must not return before the last byte is in it.
+    HIP_TRY(fetch_status(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const int complete = judge_status(c);
+    if (complete != RM_OK) return complete;          // some frame since the last check lacks tiles: nothing is copied
     if (host_pitch == row_bytes && dev_pitch == row_bytes)
         HIP_TRY(hipMemcpy(host, dev, row_bytes * c->local_rows, hipMemcpyDeviceToHost));
     else
@@ -622,7 +704,7 @@ int rm_flatten_scene(const rm_node* nodes, size_t n, rm_scene_stats* stats, char
 int rm_debug_wave_stats(rm_ctx* c, uint32_t* host_out, size_t cap_waves, size_t* n_waves) {
     if (!c || !n_waves) return RM_ERR_INVALID_ARG;
     if (!c->have_scene || !c->have_info) return RM_ERR_NOT_READY;
-    const size_t waves = static_cast<size_t>(render_blocks(c, c->jit_active && c->evaluator == 0)) * 4;
+    const size_t waves = static_cast<size_t>(render_blocks(c, c->jit_active && c->evaluator == 0, c->nframes)) * 4;
     *n_waves = waves;
     if (!host_out) return RM_OK;
     if (cap_waves < waves) return RM_ERR_INVALID_ARG;
@@ -633,10 +715,11 @@ int rm_debug_wave_stats(rm_ctx* c, uint32_t* host_out, size_t cap_waves, size_t*
     hipError_t e = hipMemsetAsync(d, 0, waves * 16, c->stream);
     if (e == hipSuccess) e = static_cast<hipError_t>(launch_frame(c, d, nullptr));
     if (e == hipSuccess) e = hipMemcpyAsync(host_out, d, waves * 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = fetch_status(c);
     hipError_t s2 = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = s2;
     (void)hipFree(d);
-    return static_cast<int>(e);
+    return e == hipSuccess ? judge_status(c) : static_cast<int>(e);
 }
 
 int rm_set_jit(rm_ctx* c, int mode) {
@@ -721,6 +804,12 @@ int rm_set_boost_age(rm_ctx* c, unsigned trips) {
     return RM_OK;
 }
 
+int rm_debug_set_watchdog(rm_ctx* c, unsigned long long ticks) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    c->watchdog = ticks ? ticks : 1ull << 36;
+    return RM_OK;
+}
+
 int rm_set_evaluator(rm_ctx* c, int which) {
     if (!c || (which != 0 && which != 1)) return RM_ERR_INVALID_ARG;
     c->evaluator = static_cast<uint32_t>(which);
@@ -739,6 +828,7 @@ const char* rm_status_string(int status) {
     case RM_ERR_NO_KERNEL: return "no gfx950 code object for this device";
     case RM_ERR_JIT: return "run-time compilation of the scene failed (see rm_jit_log)";
     case RM_ERR_ARITHMETIC: return "this device's short sqrt sequence is not IEEE sqrtf (device_math.h)";
+    case RM_ERR_INCOMPLETE: return "a frame launched since the last check did not render all its tiles (or a wavefront left on the watchdog)";
     default: return status > 0 ? hipGetErrorString(static_cast<hipError_t>(status)) : "unknown status";
     }
 }

@@ -172,10 +172,13 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // optional per-wave diagnostics (rm_debug_wave_stats): trips, normal passes, cycles
     uint32_t st_evals = 0, st_norms = 0, st_norm_cycles = 0;
     uint32_t r_base = 0, r_left = 0;         // places this wave holds in its head's cheap list (filing, below)
+    uint32_t tiles_done = 0;                 // tiles this wave rendered to the end (RM_STATUS_COUNTERS)
     const uint64_t st_t0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
 
-    // Safety net for the persistent loop: every wave leaves after 2^36 shader cycles (about half
-    // a minute) whatever state it is in, so a defect in the queue logic cannot hang the device.
+    // Safety net for the persistent loop: every wave leaves after prm.watchdog clock ticks (2^36, about
+    // ten minutes of s_memtime, unless a test lowered it) whatever state it is in, so a defect in the
+    // queue logic cannot hang the device.  It leaves a flag behind: the host reports the launch as
+    // incomplete (RM_ERR_INCOMPLETE) instead of passing its frames on.
     const uint64_t t_enter = __builtin_amdgcn_s_memtime();
     bool expired = false;
 
@@ -280,7 +283,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     else if (level == 2) __builtin_amdgcn_s_setprio(2);
                     else __builtin_amdgcn_s_setprio(3);
                 }
-                if (__builtin_amdgcn_s_memtime() - t_enter > (1ull << 36)) { expired = true; break; }
+                if (__builtin_amdgcn_s_memtime() - t_enter > kernarg_params()->watchdog) { expired = true; break; }
                 next_check = trips + 1024;
                 if (boost_on && level < RM_PRIO_LEVELS && tier(level) >= trips && tier(level) - trips < 1024) next_check = tier(level) + 1;
             }
@@ -342,6 +345,8 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             if (ep->lum) ep->lum[frame * ep->lum_frame_stride + (size_t)ly * ep->lum_pitch + (size_t)px] = (uint8_t)(pixel >> 16);
         }
 
+        ++tiles_done;
+
         // ---- file the tile under its cost for the next frame
         KernargParams* fp = kernarg_params();
         if (fp->feedback) {
@@ -374,6 +379,15 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             const uint32_t at = r_base + (RM_QUEUE_CHUNK - r_left);
             if (at < fp->list_cap) fp->lists_cur[(size_t)(home * RM_COST_BUCKETS + RM_CHEAP_BUCKET) * fp->list_cap + at] = 0xffffffffu;
         }
+    }
+
+    // what the host checks a launch against: tiles rendered, and whether the watchdog ended anything
+    if (lane == 0) {
+        uint32_t* status = kernarg_params()->status;
+        if (tiles_done)
+            __hip_atomic_fetch_add(status + (blockIdx.x & (RM_STATUS_COUNTERS - 1)) * RM_STATUS_STRIDE, tiles_done,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (expired) __hip_atomic_fetch_or(status + RM_STATUS_FLAG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     if (prm.wave_stats && lane == 0) {

@@ -45,9 +45,18 @@
 #endif
 #define RM_SET_LINES       96
 #define RM_SET_DWORDS      (RM_SET_LINES * RM_QUEUE_STRIDE)
+// Completion accounting (rm_process / rm_synchronize report RM_ERR_INCOMPLETE from it): every wavefront adds
+// the tiles it finished to one of RM_STATUS_COUNTERS running counters when it leaves (spread over that many
+// words so that the end of a launch is not 8000 atomics on one), and a wavefront that leaves on the
+// watchdog sets the flag word behind them.  The host knows how many tiles it has launched.
+#define RM_STATUS_COUNTERS 64
+#define RM_STATUS_STRIDE   16      // dwords between counters
+#define RM_STATUS_FLAG     (RM_STATUS_COUNTERS * RM_STATUS_STRIDE)
+#define RM_STATUS_DWORDS   ((RM_STATUS_COUNTERS + 1) * RM_STATUS_STRIDE)
 
 // frames one launch may render (rm_set_batch): their cameras travel in the kernarg segment
-#define RM_MAX_BATCH 8
+// (64 B each; the segment holds 4 KiB)
+#define RM_MAX_BATCH 32
 
 namespace rm {
 
@@ -77,6 +86,7 @@ struct RenderParams {
     uint8_t* hit;   size_t hit_pitch;
     uint8_t* lum;   size_t lum_pitch;   // optional luminance plane, 1 B/px (rm_set_luminance_output)
     uint32_t* wave_stats;         // optional diagnostics, 4 dwords per wavefront
+    uint32_t* status;             // RM_STATUS_DWORDS: tiles finished (running counters) and the watchdog flag
     // tile scheduler (device_render.h): this frame owns set_cur (all zero when it starts), reads the
     // lists the previous frame wrote (counts in set_prev), and zeroes set_next for the frame after it
     uint32_t* set_cur;
@@ -88,6 +98,7 @@ struct RenderParams {
     uint32_t ordered;             // 1: hand out lists_prev; 0: no history, natural tile order
     uint32_t feedback;            // 1: write lists_cur
     uint32_t boost_age;           // loop trips after which a tile raises its wave's issue priority
+    unsigned long long watchdog;  // shader clock ticks (s_memtime) after which a wavefront gives up (rm_debug_set_watchdog)
     Camera cams[RM_MAX_BATCH];    // cams[f]: frame f of the launch
 };
 

@@ -39,6 +39,29 @@ def differences(got, want):
         len(bad), want.size, bad[:8].tolist(), [int(got[tuple(i)]) for i in bad[:8]], [int(want[tuple(i)]) for i in bad[:8]])
 
 
+def assert_same_frame(rgba, hit, ref, label):
+    """RGBA8 frame AND hit mask against the oracle's, both compared before anything is asserted, so that a
+    failure says whether the pixels, the mask or both were wrong; got and want go to a file under
+    gpurun_out/ (which travels back from the GPU box) for the post-mortem."""
+    ok_rgba = np.array_equal(rgba, ref["rgba"])
+    ok_hit = hit is None or np.array_equal(hit, ref["hit"])
+    if ok_rgba and ok_hit:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "mismatch_%s.npz" % "".join(ch if ch.isalnum() else "_" for ch in str(label)))
+    np.savez_compressed(path, got_rgba=rgba, want_rgba=ref["rgba"], got_hit=hit if hit is not None else np.zeros(0, np.uint8),
+                        want_hit=ref["hit"])
+    msg = ["%s: frame differs from the oracle (dump: %s)" % (label, path)]
+    msg.append("rgba " + ("identical" if ok_rgba else differences(rgba, ref["rgba"])))
+    if hit is not None:
+        msg.append("hit mask " + ("identical" if ok_hit else differences(hit, ref["hit"])))
+        if not ok_hit:               # a tile that nobody wrote shows as an 8x8-aligned block: say which tiles
+            ys, xs = np.nonzero(hit != ref["hit"])
+            msg.append("8x8 tiles holding mask differences: %s" % sorted(set(zip((ys // 8).tolist(), (xs // 8).tolist())))[:16])
+    raise AssertionError("; ".join(msg))
+
+
 def same_floats(a, b):
     """bit-identical, except that +0 and -0 compare equal (the program
     re-associates exact min/max chains, which can only change the sign of a zero)
@@ -133,8 +156,7 @@ def test_random_trees(seed):
     ref = O.render(table, 160, 96, info)
     for path in ("jit", "jitprog", "program"):
         rgba, hit, _ = gpu_render(table, 160, 96, info, path)
-        assert np.array_equal(hit, ref["hit"]), path
-        assert np.array_equal(rgba, ref["rgba"]), path
+        assert_same_frame(rgba, hit, ref, "fuzz_%d_%s" % (seed, path))
 
 
 def test_set_rays_kat():
@@ -158,9 +180,8 @@ def test_stock_frame_640x480(stock_scenes, name, path):
     info = O.default_info(1, 0)
     rgba, hit, _ = gpu_render(stock_scenes[name], 640, 480, info, path)
     ref = O.render(stock_scenes[name], 640, 480, info, threads=min(16, os.cpu_count() or 4))
+    assert_same_frame(rgba, hit, ref, "stock_%s_%s" % (name, path))
     assert int(hit.sum()) == GOLDEN_HITS[(name, 640, 480)]
-    assert np.array_equal(hit, ref["hit"]), "hit mask differs: %d px" % int((hit != ref["hit"]).sum())
-    assert np.array_equal(rgba, ref["rgba"]), "colour differs: %d px" % int((rgba != ref["rgba"]).any(-1).sum())
     assert hashlib.sha256(O.ppm_bytes(rgba)).hexdigest() == GOLDEN_PPM[name]
     # q6: the explicit hit bit and the colour-derived mask agree on the stock scenes
     assert np.array_equal(hit.astype(bool), rgba[:, :, :3].any(-1))
@@ -212,8 +233,7 @@ def test_csg1024_frame():
     rgba, hit, _ = gpu_render(table, w, h, info, "program")
     ref = O.render(table, w, h, info, threads=min(16, os.cpu_count() or 4))
     assert ref["hit"].sum() > 0
-    assert np.array_equal(hit, ref["hit"])
-    assert np.array_equal(rgba, ref["rgba"])
+    assert_same_frame(rgba, hit, ref, "csg1024_program")
     for path in ("walker", "jit"):              # "jit": 1023 nodes, so the compiled distance program
         rgba_w, hit_w, _ = gpu_render(table, w, h, info, path)
         assert np.array_equal(rgba_w, rgba) and np.array_equal(hit_w, hit), path
@@ -232,8 +252,7 @@ def test_union_scenes_of_other_sizes(seed, leaves):
     assert ref["hit"].sum() > 0
     for path in ("jit", "program"):
         rgba, hit, _ = gpu_render(table, w, h, info, path)
-        assert np.array_equal(hit, ref["hit"]), path
-        assert np.array_equal(rgba, ref["rgba"]), path
+        assert_same_frame(rgba, hit, ref, "union_%d_%s" % (seed, path))
 
 
 @pytest.mark.parametrize("name", ["mixed_kinds", "carved", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
@@ -246,8 +265,7 @@ def test_kat_scene_frames(name, path):
     w, h = 200, 120
     rgba, hit, _ = gpu_render(table, w, h, info, path)
     ref = O.render(table, w, h, info, threads=min(16, os.cpu_count() or 4))
-    assert np.array_equal(hit, ref["hit"]), differences(hit, ref["hit"])
-    assert np.array_equal(rgba, ref["rgba"]), differences(rgba, ref["rgba"])
+    assert_same_frame(rgba, hit, ref, "kat_%s_%s" % (name, path))
 
 
 def test_ragged_sizes(stock_scenes):
@@ -256,7 +274,7 @@ def test_ragged_sizes(stock_scenes):
     for (w, h), path in [((1, 1), "jit"), ((17, 9), "program"), ((250, 131), "jit"), ((250, 131), "program")]:
         rgba, hit, _ = gpu_render(stock_scenes["chair"], w, h, info, path)
         ref = O.render(stock_scenes["chair"], w, h, info)
-        assert np.array_equal(rgba, ref["rgba"]) and np.array_equal(hit, ref["hit"])
+        assert_same_frame(rgba, hit, ref, "ragged_%dx%d_%s" % (w, h, path))
 
 
 def test_row_bands_reassemble(stock_scenes):
@@ -366,7 +384,7 @@ def test_batch_of_frames_in_one_launch(stock_scenes):
                 assert np.array_equal(rm.read_pixels(), singles[1])
                 assert np.array_equal(rm.read_hit_mask(), masks[1])
                 with pytest.raises(api.RaymarchError):
-                    rm.set_batch(9)
+                    rm.set_batch(33)
                 with pytest.raises(api.RaymarchError):
                     rm.set_info_batch(infos)                 # three blocks for a batch of two
 
@@ -389,6 +407,79 @@ def test_scene_every_ray_leaves_after_one_step():
             for launch in range(5):
                 rm.process()
                 assert np.array_equal(rm.read_pixels(), ref["rgba"]), (batch, launch)
+
+
+def test_launches_that_are_not_full(stock_scenes):
+    """rm_set_info_batch(n) with n below the batch renders n frames and touches nothing else: launches of
+    5, 2, 5, 1, 3 frames on one context (so each runs on the tile order of a launch of another length,
+    or on none where the one before was shorter), every frame against the frames rendered one by one;
+    the planes of the frames a launch does not render keep what they held."""
+    torch = pytest.importorskip("torch")
+    w, h, cap = 200, 120, 5
+    nodes = stock_scenes["chair"]
+    infos = np.concatenate([O.default_info(k + 1, 5 * k) for k in range(cap)])
+    singles = []
+    with api.Raymarching(w, h) as rm:
+        rm.set_nodes(nodes)
+        for k in range(cap):
+            rm.set_info(infos[k:k + 1])
+            rm.process()
+            singles.append(rm.read_pixels())
+    out = torch.zeros((cap, h, w, 4), dtype=torch.uint8, device="cuda")
+    for jit_mode in (2, 0):
+        with api.Raymarching(w, h) as rm:
+            rm.set_jit(jit_mode)
+            rm.set_nodes(nodes)
+            rm.set_output(out.data_ptr(), w * 4)
+            rm.set_batch(cap, h * w * 4, 0)
+            for n in (5, 2, 5, 1, 3):
+                out.fill_(0x5a)
+                order = list(range(cap))[-n:] + list(range(cap))[:-n]          # another camera per slot each time
+                rm.set_info_batch(infos[order[:n]])
+                rm.process()
+                got = out.cpu().numpy()
+                for slot in range(n):
+                    assert np.array_equal(got[slot], singles[order[slot]]), (jit_mode, n, slot)
+                assert (got[n:] == 0x5a).all(), (jit_mode, n)
+            rm.set_info(infos[0:1])                                       # all five frames again, one camera
+            rm.process()
+            got = out.cpu().numpy()
+            for slot in range(cap):
+                assert np.array_equal(got[slot], singles[0])
+
+
+def test_incomplete_frame_is_reported(stock_scenes):
+    """A wavefront that leaves on its watchdog must not pass for a finished frame: with the watchdog at
+    one tick every tile of more than a few trips is abandoned, rm_process / rm_synchronize / rm_read_pixels
+    return RM_ERR_INCOMPLETE, and the next frame (watchdog restored) is whole and in order again."""
+    info = O.default_info(1, 0)
+    w, h = 320, 200
+    ref = O.render(stock_scenes["chair"], w, h, info, threads=min(16, os.cpu_count() or 4))
+    for jit_mode in (2, 0):
+        with api.Raymarching(w, h) as rm:
+            rm.set_jit(jit_mode)
+            rm.set_nodes(stock_scenes["chair"])
+            rm.set_info(info)
+            rm.enable_hit_mask(True)
+            rm.process()
+            assert_same_frame(rm.read_pixels(), rm.read_hit_mask(), ref, "before_watchdog")
+            rm.set_boost_age(4)                     # the clock is looked at where the priority steps up: trip 5
+            rm.set_watchdog(1)
+            with pytest.raises(api.RaymarchError) as e:
+                rm.process()
+            assert e.value.status == -10
+            rm.process_async()
+            with pytest.raises(api.RaymarchError) as e:
+                rm.synchronize()
+            assert e.value.status == -10
+            rm.process_async()
+            with pytest.raises(api.RaymarchError) as e:
+                rm.read_pixels()
+            assert e.value.status == -10
+            rm.set_watchdog(0)
+            for k in range(3):                      # natural order, then the order learnt from it
+                rm.process()
+                assert_same_frame(rm.read_pixels(), rm.read_hit_mask(), ref, "after_watchdog_%d" % k)
 
 
 def test_external_output_and_pitch(stock_scenes):

@@ -267,3 +267,53 @@ def test_generated_code_compiles_for_gfx950_without_a_device(name, stock_scenes)
         assert name in ("carved", "deep_values") and "return n0(p)" in src and "struct SceneKeep" not in src
     else:                             # the fused pair over kept temporaries
         assert name != "carved" and "struct SceneKeep" in src and "scene_norm_keep" in src
+
+
+class _FakeContext:
+    """Records the C-ABI calls bench.py's render loop makes on a context."""
+    def __init__(self, log, name):
+        self.log, self.name = log, name
+
+    def set_batch(self, *a):
+        self.log.append((self.name, "set_batch", a[0]))
+
+    def set_info_batch(self, infos):
+        self.log.append((self.name, "set_info_batch", len(infos)))
+
+    def process_async(self):
+        self.log.append((self.name, "process_async", None))
+
+
+@pytest.mark.parametrize("steps,batch,contexts,want", [(20, 8, 1, [8, 8, 4]), (13, 4, 1, [4, 4, 4, 1]), (16, 8, 1, [8, 8]),
+                                                       (21, 8, 3, [8, 8, 5]), (3, 32, 2, [3])])
+def test_a_launch_that_is_not_full_sets_no_batch(steps, batch, contexts, want):
+    """The driver times `--steps 20` with 8 frames per launch: launches of 8, 8 and 4 frames.  The last
+    one must take its frame count from rm_set_info_batch alone - rm_set_batch inside the timed region
+    waited for the stream, reallocated the scheduler and dropped the tile order."""
+    from raytracing_amd.batching import FrameBatcher
+    log = []
+    ctxs = [_FakeContext(log, j) for j in range(contexts)]
+    seen = []
+    run = FrameBatcher(ctxs, batch, before=lambda j: seen.append(("before", j)), after=lambda j, n: seen.append(("after", j, n)))
+    info = np.zeros(1, dtype=api.INFO_DTYPE)
+    for k in range(steps):
+        run.step(info)
+    run.flush()
+    run.flush()                                         # nothing pending: no launch
+    assert [n for _, call, n in log if call == "set_info_batch"] == want
+    assert [call for _, call, _ in log].count("process_async") == len(want) == run.launches
+    assert not [c for c in log if c[1] == "set_batch"]
+    assert [name for name, call, _ in log if call == "process_async"] == [k % contexts for k in range(len(want))]
+    assert run.last == ((len(want) - 1) % contexts, want[-1] - 1)
+    assert seen == [x for k, n in enumerate(want) for x in (("before", k % contexts), ("after", k % contexts, n))]
+
+
+def test_bench_sets_the_batch_once_before_timing():
+    """bench.py itself: rm_set_batch appears once, ahead of the warm-up, and the oracle is imported only
+    for the CPU baseline (the camera block comes from the committed fixture)."""
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        text = f.read()
+    assert text.count(".set_batch(") == 1 and text.index(".set_batch(") < text.index("# Warm-up")
+    assert text.count("from oracle import") == 1 and text.index("from oracle import") < text.index("def main()")
+    blocks = np.fromfile(os.path.join(ROOT, "tests", "golden", "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
+    assert blocks[0:1].tobytes() == O.default_info(1, 0).tobytes()

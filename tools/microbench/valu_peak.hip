@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) NAME(float* out, float seed, unsigned lon
     unsigned long long t0 = __builtin_amdgcn_s_memtime(); \
     for (int i = 0; i < N_ITER; ++i) { \
         REP8(asm volatile(TXT(0) TXT(1) TXT(2) TXT(3) TXT(4) TXT(5) TXT(6) TXT(7) \
-             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(sc) : "vcc");) \
+             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "s"(sc) : "vcc", "s20", "s21", "s22", "s23");) \
     } \
     unsigned long long t1 = __builtin_amdgcn_s_memtime(); \
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; \
@@ -83,6 +83,27 @@ __global__ void __launch_bounds__(256) NAME(float* out, float seed, unsigned lon
 #define T_ADDABS(n)   "v_add_f32_e64 %" #n ", |%" #n "|, %9\n"
 #define T_SUBNEG(n)   "v_sub_f32 %" #n ", %8, %" #n "\n"
 #define T_MOV(n)      "v_mov_b32 %" #n ", %8\n"
+#define T_ADDU(n)     "v_add_u32 %" #n ", 0x80800000, %" #n "\n"
+#define T_CMPU(n)     "v_cmp_gt_u32 vcc, %9, %" #n "\n"
+#define T_MAX3(n)     "v_max3_f32 %" #n ", %" #n ", %8, %8\n"
+#define T_MAX3N(n)    "v_max3_f32 %" #n ", %" #n ", -%8, -%8\n"
+#define T_MIN3U(n)    "v_min3_u32 %" #n ", %" #n ", %8, %8\n"
+#define T_CNDS(n)     "v_cndmask_b32 %" #n ", %" #n ", %8, s[20:21]\n"
+#define T_CMPCND(n)   "v_cmp_lt_f32 vcc, %" #n ", %8\n v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define T_MULLEG(n)   "v_mul_legacy_f32 %" #n ", %" #n ", %8\n"
+#define T_MAXLIT(n)   "v_max_f32 %" #n ", 0, %" #n "\n"
+#define T_OR(n)       "v_or_b32 %" #n ", %" #n ", %8\n"
+#define T_CVT(n)      "v_cvt_i32_f32 %" #n ", %" #n "\n"
+#define T_CMPS(n)     "v_cmp_lt_f32 s[22:23], %" #n ", %8\n"
+#define T_CMPX(n)     "v_cmp_class_f32 vcc, %" #n ", %8\n"
+#define T_MULADD(n)   "v_mul_f32 %" #n ", %" #n ", %8\n v_max_f32 %" #n ", %" #n ", %8\n"
+#define T_FMAK(n)     "v_fmaak_f32 %" #n ", %" #n ", %8, 0x3f1ce861\n"
+#define T_MADMK(n)    "v_fmamk_f32 %" #n ", %" #n ", 0x3f1ce861, %8\n"
+#define T_FMA3(n)     "v_fma_f32 %" #n ", %" #n ", %8, %" #n "\n"
+#define T_FMAS(n)     "v_fma_f32 %" #n ", %" #n ", %9, %8\n"
+GEN(g_addu, T_ADDU) GEN(g_cmpu, T_CMPU) GEN(g_max3, T_MAX3) GEN(g_max3n, T_MAX3N) GEN(g_min3u, T_MIN3U) GEN(g_cnds, T_CNDS)
+GEN(g_cmpcnd, T_CMPCND) GEN(g_mulleg, T_MULLEG) GEN(g_maxlit, T_MAXLIT) GEN(g_or, T_OR) GEN(g_cvt, T_CVT) GEN(g_cmps, T_CMPS)
+GEN(g_cmpx, T_CMPX) GEN(g_muladd, T_MULADD) GEN(g_fmak, T_FMAK) GEN(g_madmk, T_MADMK) GEN(g_fma3, T_FMA3) GEN(g_fmas, T_FMAS)
 GEN(g_mul_lit, T_MUL_LIT) GEN(g_add_sgpr, T_ADD_SGPR) GEN(g_fmac, T_FMAC) GEN(g_fma_lit, T_FMA_LIT) GEN(g_max, T_MAX)
 GEN(g_med3, T_MED3) GEN(g_cmp32, T_CMP32) GEN(g_cnd32, T_CND32) GEN(g_rsq, T_RSQ) GEN(g_floor, T_FLOOR)
 GEN(g_and, T_AND) GEN(g_addabs, T_ADDABS) GEN(g_sub, T_SUBNEG) GEN(g_mov, T_MOV)
@@ -124,9 +145,36 @@ void run(const char* name, int waves_per_simd, float* d_out, unsigned long long*
            total_instr * 64 * flops_per_instr / (ms * 1e-3) / 1e12, mean / (ms * 1e-3) / 1e9);
 }
 
-int main() {
+int main(int argc, char** argv) {
     float* d_out; unsigned long long* d_cyc;
     hipMalloc(&d_out, 256 * 8 * 256 * 4); hipMalloc(&d_cyc, 256 * 8 * 8);
+    if (argc > 1) {          // round 2: the instruction kinds of the march loop's tests and selects, 8 waves per SIMD
+        const int w = 8;
+        run_gen("v_add_f32 (ref)", g_add_sgpr, w, d_out, d_cyc);
+        run_gen("v_add_u32 lit", g_addu, w, d_out, d_cyc);
+        run_gen("v_cmp_gt_u32", g_cmpu, w, d_out, d_cyc);
+        run_gen("v_max3_f32", g_max3, w, d_out, d_cyc);
+        run_gen("v_max3 neg", g_max3n, w, d_out, d_cyc);
+        run_gen("v_min3_u32", g_min3u, w, d_out, d_cyc);
+        run_gen("v_cndmask sgpr", g_cnds, w, d_out, d_cyc);
+        run_gen("cmp+cnd pair/2", g_cmpcnd, w, d_out, d_cyc);
+        run_gen("v_mul_legacy", g_mulleg, w, d_out, d_cyc);
+        run_gen("v_max 0 lit", g_maxlit, w, d_out, d_cyc);
+        run_gen("v_or_b32", g_or, w, d_out, d_cyc);
+        run_gen("v_cvt_i32_f32", g_cvt, w, d_out, d_cyc);
+        run_gen("v_cmp sgpr dst", g_cmps, w, d_out, d_cyc);
+        run_gen("v_cmp_class", g_cmpx, w, d_out, d_cyc);
+        run_gen("mul+max pair/2", g_muladd, w, d_out, d_cyc);
+        run_gen("v_fmaak", g_fmak, w, d_out, d_cyc);
+        run_gen("v_fmamk", g_madmk, w, d_out, d_cyc);
+        run_gen("v_fma a,b,a", g_fma3, w, d_out, d_cyc);
+        run_gen("v_fma sgpr", g_fmas, w, d_out, d_cyc);
+        run_gen("v_max_f32", g_max, w, d_out, d_cyc);
+        run_gen("v_rsq_f32", g_rsq, w, d_out, d_cyc);
+        run_gen("v_floor_f32", g_floor, w, d_out, d_cyc);
+        run_gen("v_fmac vop2", g_fmac, w, d_out, d_cyc);
+        return 0;
+    }
     for (int w : {1, 2, 4, 8}) {
         run<0>("v_add_f32", w, d_out, d_cyc, 1);
         run<1>("v_pk_add_f32", w, d_out, d_cyc, 2);
