@@ -154,6 +154,23 @@ int rm_enable_hit_mask(rm_ctx* ctx, int enable);
  * stream events as a float; the reference returns it truncated to whole ms. */
 int rm_process(rm_ctx* ctx, float* elapsed_ms);
 
+/* rm_process for callers that cannot allocate.  It has no counterpart in the
+ * reference: it is for code under HIP graph capture, tight serving loops and
+ * harnesses that forbid hipMalloc.  One frame of the context's scene, camera
+ * `info`, into the caller's DEVICE buffer (RGBA8 rows `pitch_bytes` apart, as
+ * rm_set_output), waited for like rm_process, same pixels.  The call itself
+ * allocates nothing: the tile scheduler's scratch (counter sets, tile lists,
+ * completion counters), which a context otherwise gets from hipMalloc, lives in a
+ * file-scope device array of the library, 9.5 MB on every GPU it runs on, whose
+ * device address rm_create looks up once per device.  Limits: one frame per call,
+ * at most 131 072 tiles of 8x8 pixels (8.39 Mpixels of this context's rows: a
+ * 3840x2160 frame fits, 7680x4320 does not -> RM_ERR_TOO_LARGE); no hit mask, no
+ * luminance plane.  All calls on one GPU share that GPU's array (the tile order
+ * learnt by one call serves the next one of the same image size): calls of one
+ * process take their turn under a lock; anything else that overlaps on one GPU
+ * races. */
+int rm_process_static(rm_ctx* ctx, const rm_rays_info* info, void* device_rgba, size_t pitch_bytes, float* elapsed_ms);
+
 /* Same launch without events and without waiting: for back-to-back frames
  * timed by the caller on the context's stream. */
 int rm_process_async(rm_ctx* ctx);

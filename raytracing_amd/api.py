@@ -30,7 +30,7 @@ EXPORTS = [
     "rm_flatten_scene", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
     "rm_set_luminance_output", "rm_assemble_luminance", "rm_set_batch", "rm_set_info_batch",
-    "rm_debug_set_watchdog",
+    "rm_process_static", "rm_debug_set_watchdog",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
             "rm_local_rows": [vp, C.POINTER(sz)],
             "rm_enable_hit_mask": [vp, i32],
             "rm_process": [vp, C.POINTER(C.c_float)],
+            "rm_process_static": [vp, vp, vp, sz, C.POINTER(C.c_float)],
             "rm_process_async": [vp],
             "rm_synchronize": [vp],
             "rm_read_pixels": [vp, vp, sz],
@@ -290,6 +291,13 @@ class Raymarching:
         """Render one frame and wait; returns the kernel time in ms."""
         ms = C.c_float(0)
         _check(lib().rm_process(self._ctx, C.byref(ms)), "rm_process")
+        return ms.value
+
+    def process_static(self, info, device_ptr, pitch_bytes):
+        """One frame into a caller-owned device buffer through the entry point that allocates nothing; kernel ms."""
+        info = np.ascontiguousarray(info, dtype=INFO_DTYPE)
+        ms = C.c_float(0)
+        _check(lib().rm_process_static(self._ctx, _ptr(info), C.c_void_p(device_ptr), pitch_bytes, C.byref(ms)), "rm_process_static")
         return ms.value
 
     def process_async(self):

@@ -354,6 +354,20 @@ int grow_framebuffer(rm_ctx* c, size_t frames) {
     return RM_OK;
 }
 
+// ---- rm_process_static: the scheduler block in the library's file-scope device array ----------
+// One per device (raymarch_kernels.hip: static_scratch_address).  Every call on a device shares that
+// device's block, so the state that says what the block holds is per device too, and the calls of
+// one process take their turn under one lock.
+struct StaticSched {
+    uint32_t* ptr = nullptr;          // device address of this device's copy of the array
+    uint32_t seq = 0;                 // launches so far (the counter sets rotate as a context's do)
+    bool history = false;             // the lists of launch seq-1 hold every tile of a frame of...
+    size_t width = 0, local_rows = 0; // ...this tile numbering
+    uint32_t expected_done = 0;       // tiles launched so far, modulo 2^32
+};
+std::mutex g_static_mutex;
+std::map<int, StaticSched> g_static;
+
 }  // namespace
 
 extern "C" {
@@ -407,6 +421,17 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
             int rc = sqrt_sweep(c, 0x3f800000u, 1ull << 24, &bad);
             if (rc != RM_OK || bad != 0) { rm_destroy(c); return rc != RM_OK ? rc : RM_ERR_ARITHMETIC; }
             proved.insert(device);
+        }
+    }
+    // rm_process_static's scheduler block: its address on this device, looked up once, here at set-up
+    {
+        std::lock_guard<std::mutex> lock(g_static_mutex);
+        StaticSched& st = g_static[device];
+        if (!st.ptr) {
+            hipError_t se = rm::static_scratch_address(device, &st.ptr);
+            if (se == hipSuccess) se = hipMemset(st.ptr, 0, (3 * RM_SET_DWORDS) * sizeof(uint32_t));
+            if (se == hipSuccess) se = hipMemset(st.ptr + RM_STATIC_DWORDS - RM_STATUS_DWORDS, 0, RM_STATUS_DWORDS * sizeof(uint32_t));
+            if (se != hipSuccess) { st.ptr = nullptr; rm_destroy(c); return static_cast<int>(se); }
         }
     }
     c->out = c->fb; c->out_pitch = width * 4;
@@ -622,6 +647,51 @@ int rm_process(rm_ctx* c, float* elapsed_ms) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
     return judge_status(c);
+}
+
+int rm_process_static(rm_ctx* c, const rm_rays_info* info, void* device_rgba, size_t pitch_bytes, float* elapsed_ms) {
+    if (!c || !info || !device_rgba) return RM_ERR_INVALID_ARG;
+    if (pitch_bytes < c->width * 4 || (pitch_bytes & 3) || (reinterpret_cast<uintptr_t>(device_rgba) & 3)) return RM_ERR_INVALID_ARG;
+    if (!c->have_scene) return RM_ERR_NOT_READY;
+    if (!c->d_program || !c->d_tree || c->n_nodes != c->scene.tree.size() || c->local_rows > c->height) return RM_ERR_INVALID_ARG;
+    const size_t tiles = local_tiles(c);
+    if (tiles > RM_STATIC_MAX_TILES) return RM_ERR_TOO_LARGE;        // the array holds lists for that many tiles, no more
+    if (c->local_rows == 0) return RM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    StaticSched& st = g_static[c->device];
+    if (!st.ptr) return RM_ERR_NOT_READY;                            // rm_create looked it up: cannot happen
+    rm::RenderParams p;
+    fill_params(c, p);
+    p.rgba = static_cast<uint8_t*>(device_rgba); p.pitch = pitch_bytes;
+    p.hit = nullptr; p.lum = nullptr; p.wave_stats = nullptr;
+    p.nframes = 1;
+    camera_from(info, p.cams[0]);
+    point_at_schedule(p, st.ptr, st.seq, RM_STATIC_LIST_CAP, RM_STATIC_MAX_TILES);
+    p.ordered = (c->feedback && st.history && st.width == c->width && st.local_rows == c->local_rows) ? 1u : 0u;
+    const bool jit = c->jit_active && c->evaluator == 0;
+    const unsigned blocks = render_blocks(c, jit, 1);
+    // The block keeps what the last call on this device left in it.  This launch's own counter set must
+    // start at zero (a launch zeroes the set of the launch after it, but the call before this one may
+    // have failed half-way); the lists and the previous set are read only when `ordered` says they are sound.
+    HIP_TRY(hipMemsetAsync(p.set_cur, 0, RM_SET_DWORDS * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(jit ? rm::jit_launch_render(c->jit, p, blocks, c->stream) : rm::launch_render(p, blocks, c->lds_bytes, c->stream));
+    ++st.seq;
+    st.history = c->feedback; st.width = c->width; st.local_rows = c->local_rows;
+    st.expected_done += static_cast<uint32_t>(tiles);
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->status_host, p.status, RM_STATUS_DWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    uint32_t done = 0;
+    for (int k = 0; k < RM_STATUS_COUNTERS; ++k) done += c->status_host[k * RM_STATUS_STRIDE];
+    if (done == st.expected_done && c->status_host[RM_STATUS_FLAG] == 0) return RM_OK;
+    st.expected_done = done;
+    st.history = false;
+    (void)hipMemsetAsync(p.status + RM_STATUS_FLAG, 0, sizeof(uint32_t), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    return RM_ERR_INCOMPLETE;
 }
 
 // Device rows to host memory.  Rows that are contiguous on both sides go as one linear copy: into pageable

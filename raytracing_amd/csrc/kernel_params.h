@@ -54,6 +54,14 @@
 #define RM_STATUS_FLAG     (RM_STATUS_COUNTERS * RM_STATUS_STRIDE)
 #define RM_STATUS_DWORDS   ((RM_STATUS_COUNTERS + 1) * RM_STATUS_STRIDE)
 
+// rm_process_static (the entry point that allocates nothing) keeps its scheduler block - three counter sets,
+// two list groups, a status block, laid out as a context's - in a file-scope device array of
+// raymarch_kernels.hip: room for RM_STATIC_MAX_TILES tiles (8.39 Mpixels: a 3840x2160 frame has 129 600),
+// lists of an eighth of that per head and bucket plus the overflow list; 9.5 MB on every GPU the library runs on.
+#define RM_STATIC_MAX_TILES 131072
+#define RM_STATIC_LIST_CAP  (RM_STATIC_MAX_TILES / 8 + 16)
+#define RM_STATIC_DWORDS    (3 * RM_SET_DWORDS + 2 * (RM_QUEUE_HEADS * RM_COST_BUCKETS * RM_STATIC_LIST_CAP + RM_STATIC_MAX_TILES) + RM_STATUS_DWORDS)
+
 // frames one launch may render (rm_set_batch): their cameras travel in the kernarg segment
 // (64 B each; the segment holds 4 KiB)
 #define RM_MAX_BATCH 32
@@ -112,6 +120,8 @@ hipError_t launch_eval_rays(const RenderParams& prm, const int* xy, uint32_t cou
 // raise the kernels' dynamic-LDS ceiling when a scene needs more than the 64 KiB default
 hipError_t configure_lds(size_t lds_bytes);
 hipError_t kernel_attributes(int* vgprs, int* scratch_bytes);
+// device address of the static scheduler block (RM_STATIC_DWORDS dwords) on `device`, which must be current
+hipError_t static_scratch_address(int device, uint32_t** ptr);
 // enumeration proofs of device_math.h's short sqrt / quotient sequences (mismatch counts in *bad)
 // luminance planes of `nranks` band-interleaved parts -> one RGBA8 frame (rm_assemble_luminance)
 hipError_t launch_assemble_luminance(const uint8_t* parts, size_t rank_stride, size_t part_pitch, uint32_t width, uint32_t height,

@@ -18,10 +18,41 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <mutex>
+
 #include "device_interp.h"
 #include "device_render.h"
 
 namespace rm {
+
+// =============================================================================
+// Scheduler block of rm_process_static, the entry point that allocates nothing
+// (include/raymarching_amd.h): counter sets, tile lists and status block that a
+// context otherwise gets from hipMalloc.  Every GPU the library runs on holds its
+// own copy of this array at its own address until the process ends.  In host code
+// the array's NAME is only a handle for hipGetSymbolAddress - passing it to a
+// kernel would hand the device a host address - so the address is looked up once
+// per device, with that device current (rm_create does it), and only that
+// pointer is ever used: as kernel argument, for hipMemsetAsync, for copies.
+// =============================================================================
+static __device__ __align__(256) __attribute__((used)) uint32_t scratch[RM_STATIC_DWORDS];
+
+hipError_t static_scratch_address(int device, uint32_t** ptr) {
+    static std::mutex mu;
+    static std::map<int, uint32_t*> known;        // device -> address of its copy
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find(device);
+    if (it == known.end()) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        it = known.emplace(device, static_cast<uint32_t*>(p)).first;
+    }
+    *ptr = it->second;
+    return hipSuccess;
+}
 
 __global__ void __launch_bounds__(RM_BLOCK_THREADS)
 render_kernel(const RenderParams prm) {
