@@ -14,6 +14,12 @@ struct P3 { float x, y, z; };
 __device__ __forceinline__ float as_f(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __builtin_bit_cast(uint32_t, f); }
 
+// This lane's bit of a wave-level mask held in scalar registers (the inverse of a ballot): the mask is
+// used as the branch's or select's condition as it is, no vector instruction.  The compiler's builtin for
+// it is missing from the hiprtc of ROCm 7.0 that a process with PyTorch loads, so the intrinsic is
+// declared by name.
+extern "C" __device__ bool rm_lane_of_mask(unsigned long long) __asm("llvm.amdgcn.inverse.ballot.i64");
+
 // ---- correctly rounded sqrt and constant-divisor division in fewer instructions ---------------
 //
 // hipcc expands IEEE sqrtf into ~16 VALU instructions and '/' into ~12; a march step of
@@ -206,7 +212,5 @@ __device__ __forceinline__ void make_ray(const Camera& cam, uint32_t width, uint
 __device__ __forceinline__ uint32_t to_u8(float v) {
     return !(v > -1.f) ? 0u : (v >= 256.f ? 255u : (uint32_t)(int)v);
 }
-
-enum : int { M_PRIMARY = 0, M_SHADOW = 1, M_DONE = 2 };
 
 }  // namespace rm

@@ -209,7 +209,16 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         P3 pos, rd;
         make_ray(cam, width, height, (int)px, (int)gy, pos, rd);
         float t = 0.f, cd = 0.f, n_l = 0.f, shadow = 1.f;
-        int mode = in_image ? M_PRIMARY : M_DONE, steps = 0;
+        // Which lanes march, and in which phase, is two wave-level masks in scalar registers, not a mode
+        // per lane: the tests on them, their updates and the branches they feed are scalar instructions,
+        // which issue beside the vector ones, and a compare or select costs 1.7 vector additions here
+        // (tools/microbench/valu_peak.hip).  m_p: lanes on their primary march (:626); m_s: lanes on
+        // their shadow march (:660).  A lane in neither is done.
+        unsigned long long m_p = __builtin_amdgcn_ballot_w64(in_image), m_s = 0;
+        // The step caps (:626 I < 500, :660 J < 300) need no counter per lane either: a lane moves every
+        // trip it is in a phase, every lane starts its primary march at trip 1 (so its step count is the
+        // wave's trip count), and a lane that turns to the light at trip s has made J steps at trip s + J.
+        uint32_t deadline = 0;                   // shadow lanes: the trip that is their step RM_SHADOW_STEPS
         // what a shaded lane carries out of the loop: its luminance byte L (:694) under a flag bit; the pixel
         // is a function of L alone and is put together once, after the loop (one loop-carried value, not two)
         uint32_t shaded = 0;
@@ -224,53 +233,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         const bool boost_on = boost_age < (1u << 24);
         auto tier = [&](uint32_t k) { return k == 0 ? boost_age : k == 1 ? RM_PRIO_STEP2 * boost_age : RM_PRIO_STEP3 * boost_age; };
         uint32_t next_check = boost_age < 1023 ? boost_age + 1 : 1024;
-
-        // the two places a normal is consumed (Source/cuda_kernels.cu:640-658 and :673-691)
-        auto advance_primary = [&]() {                                             // :707-714
-            pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
-            t += cd;
-            ++steps;
-            if (t >= RM_MAX_DIST || steps >= RM_PRIMARY_STEPS) mode = M_DONE;
-        };
-        auto finish = [&]() {                                                      // :693-701
-            float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
-            shaded = 0x100u | to_u8(lum);
-            mode = M_DONE;
-        };
-        auto shadow_tail = [&]() {                                                 // :679-690
-            // shadow = min(shadow, (128*cd)/t).  The quotient matters only when it is below `shadow`, and
-            // most steps it is not: n > shadow*t, by a margin that covers the product's rounding, means
-            // n/t > shadow in exact arithmetic, so the rounded quotient is >= shadow and min() keeps
-            // `shadow` bit for bit.  Only the other lanes pay for the division (12 instructions).
-            const float n = RM_HARDNESS * cd, st = shadow * t;
-            if (!(n > st + fabsf(st) * 4.8e-7f)) {
-                float ns = n;
-                asm volatile("; shadow quotient" : "+v"(ns));           // a branch, not a select over a speculated division
-                shadow = min2(shadow, ns / t);
-            }
-            if (shadow < 0.01f) { finish(); return; }
-            pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
-            t += cd;
-            ++steps;
-            if (t >= RM_MAX_DIST || steps >= RM_SHADOW_STEPS) finish();
-        };
-        auto primary_normal = [&](P3 n) {                                          // :640-658
-            if (dot3(n.x, n.y, n.z, rd.x, rd.y, rd.z) < 0.f) {
-                n_l = dot3(n.x, n.y, n.z, light.x, light.y, light.z);
-                shadow = 1.f;
-                const float k = (1 + RM_DELTA) * RM_MIN_DIST;
-                pos.x += k * light.x; pos.y += k * light.y; pos.z += k * light.z;
-                t = k;
-                mode = M_SHADOW;
-                steps = 0;
-            } else {
-                advance_primary();
-            }
-        };
-        auto shadow_normal = [&](P3 n) {                                           // :673-676
-            if (dot3(n.x, n.y, n.z, rd.x, rd.y, rd.z) < RM_MIN_DIST) { shadow = 0.f; finish(); }
-            else shadow_tail();
-        };
+        auto lanes = [](unsigned long long m) { return rm_lane_of_mask(m); };   // this lane's bit of a mask
 
         for (;;) {
             // One compare per trip for the two things that happen rarely: a tile that runs long goes
@@ -288,44 +251,100 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 if (boost_on && level < RM_PRIO_LEVELS && tier(level) >= trips && tier(level) - trips < 1024) next_check = tier(level) + 1;
             }
 
-            const bool active = mode != M_DONE;
-            if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-            bool need = false;                       // this lane wants NORM(root, pos) before it goes on
+            const unsigned long long marching = m_p | m_s;
+            if (marching == 0) break;
             ++st_evals;
             // DIST(root, pos) for the whole wave (:627 and :661 share this)
             const P3 at = pos;
             typename Scene::Keep keep;
-            cd = scene.dist_keep(at, scratch, active, keep);     // every lane: nothing reads a resting lane's value
-            if (active) {
-                if (mode == M_PRIMARY) {
-                    if (cd < RM_MIN_DIST) {                                    // :629
-                        if (cd < -0.f) primary_normal(P3{-rd.x, -rd.y, -rd.z});  // :630-633
-                        else need = true;
-                    } else {
-                        advance_primary();
+            cd = scene.dist_keep(at, scratch, lanes(marching), keep);     // every lane: nothing reads a resting lane's value
+
+            // lanes at a surface: cd < RM_MIN_DIST on the primary march (:629), 8 * cd < RM_MIN_DIST on the shadow march (:662)
+            unsigned long long near = __builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p;
+            if (m_s) near |= __builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s;
+
+            // ---- rare: some lane is at a surface.  It takes its normal in this trip, at the point the distance
+            // was just evaluated at: the normal's transforms and child distances are the ones computed above
+            // (Scene::Keep).  Then it either turns (primary -> shadow, shadow -> done) or marches on with the others.
+            unsigned long long turn = 0, occluded = 0;          // primary lanes that turn to the light; shadow lanes behind an occluder
+            if (near) {
+                const uint64_t st_n0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
+                ++st_norms;
+                bool turns = false, hidden = false;
+                if (lanes(near)) {
+                    const bool in_shadow = lanes(m_s);
+                    // inside the surface the march direction stands in for the normal (:630-633, :663-666)
+                    P3 n = in_shadow ? P3{-light.x, -light.y, -light.z} : P3{-rd.x, -rd.y, -rd.z};
+                    if (!(cd < -0.f)) {                                                // :635-637, :668-670
+                        P3 N = scene.norm_keep(at, scratch, keep);
+                        float R_1 = r_length_3(N.x, N.y, N.z);
+                        n = P3{R_1 * N.x, R_1 * N.y, R_1 * N.z};
                     }
-                } else {
-                    if (8 * cd < RM_MIN_DIST) {                                // :662
-                        if (cd < -0.f) shadow_normal(P3{-light.x, -light.y, -light.z});   // :663-666
-                        else need = true;
-                    } else {
-                        shadow_tail();
+                    const float facing = dot3(n.x, n.y, n.z, rd.x, rd.y, rd.z);
+                    if (in_shadow) {                                                   // :673-676
+                        if (facing < RM_MIN_DIST) { shadow = 0.f; hidden = true; }
+                    } else if (facing < 0.f) {                                         // :640-658
+                        n_l = dot3(n.x, n.y, n.z, light.x, light.y, light.z);
+                        shadow = 1.f;
+                        const float k = (1 + RM_DELTA) * RM_MIN_DIST;
+                        pos.x += k * light.x; pos.y += k * light.y; pos.z += k * light.z;
+                        t = k;
+                        deadline = trips + RM_SHADOW_STEPS;
+                        turns = true;
                     }
                 }
+                turn = __builtin_amdgcn_ballot_w64(turns);
+                occluded = __builtin_amdgcn_ballot_w64(hidden);
+                if (prm.wave_stats) st_norm_cycles += (uint32_t)(__builtin_amdgcn_s_memtime() - st_n0);
             }
-            // Lanes that reached a surface take their normal in the same trip, at the point the
-            // distance was just evaluated at (a waiting lane does not move): the normal's transforms
-            // and child distances are the ones computed above, and the compiler shares them.
-            if (__builtin_amdgcn_ballot_w64(need) == 0) continue;
-            const uint64_t st_n0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
-            ++st_norms;
-            if (need) {                                                            // :635-637, :668-670
-                P3 N = scene.norm_keep(at, scratch, keep);
-                float R_1 = r_length_3(N.x, N.y, N.z);
-                P3 n{R_1 * N.x, R_1 * N.y, R_1 * N.z};
-                if (mode == M_PRIMARY) primary_normal(n); else shadow_normal(n);
+
+            // ---- primary lanes march on (:707-714), those that did not just turn to the light
+            const unsigned long long go_p = m_p & ~turn;
+            unsigned long long left_p = 0;
+            if (go_p) {
+                if (lanes(go_p)) {
+                    pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
+                    t += cd;
+                }
+                left_p = trips >= RM_PRIMARY_STEPS ? go_p : (__builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST) & go_p);
             }
-            if (prm.wave_stats) st_norm_cycles += (uint32_t)(__builtin_amdgcn_s_memtime() - st_n0);
+
+            // ---- shadow lanes march on (:679-690), those not found behind an occluder
+            const unsigned long long go_s = m_s & ~occluded;
+            unsigned long long left_s = 0;
+            if (go_s) {
+                bool ends = false;
+                if (lanes(go_s)) {
+                    // shadow = min(shadow, (128*cd)/t).  The quotient matters only when it is below `shadow`, and
+                    // most steps it is not: n > shadow*t, by a margin that covers the product's rounding, means
+                    // n/t > shadow in exact arithmetic, so the rounded quotient is >= shadow and min() keeps
+                    // `shadow` bit for bit.  Only the other lanes pay for the division (12 instructions).
+                    const float n = RM_HARDNESS * cd, st = shadow * t;
+                    if (!(n > st + fabsf(st) * 4.8e-7f)) {
+                        float ns = n;
+                        asm volatile("; shadow quotient" : "+v"(ns));           // a branch, not a select over a speculated division
+                        shadow = min2(shadow, ns / t);
+                    }
+                    if (shadow < 0.01f) ends = true;
+                    else {
+                        pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
+                        t += cd;
+                        ends = t >= RM_MAX_DIST || trips >= deadline;
+                    }
+                }
+                left_s = __builtin_amdgcn_ballot_w64(ends) & go_s;
+            }
+
+            // ---- lanes whose shadow march ended are shaded (:693-701)
+            const unsigned long long fin = occluded | left_s;
+            if (fin) {
+                if (lanes(fin)) {
+                    float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
+                    shaded = 0x100u | to_u8(lum);
+                }
+            }
+            m_p = go_p & ~left_p;
+            m_s = (go_s & ~left_s) | turn;
         }
         if (level) __builtin_amdgcn_s_setprio(0);
         if (expired) break;

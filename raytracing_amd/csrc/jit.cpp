@@ -3,6 +3,7 @@
 
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,9 @@ rm_eval_points_jit(const rm::RenderParams prm, const float* __restrict__ xyz, ui
     if (live) p = rm::P3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     rm::JitScene::Keep keep;
     const float d = scene.dist_keep(p, scratch, live, keep);          // wave-uniform code: every lane runs it
+    // The march takes a normal only where the distance says a surface is near; this hook takes one at every point,
+    // so its distance pass may not skip what the march's may (Fused::bound_skip)
+    if (norm_out) (void)scene.dist_keep_all(p, scratch, live, keep);
     if (live) {
         dist_out[i] = d;
         if (norm_out) {
@@ -106,8 +110,20 @@ struct Fused {
     const DivisorSet* exact;
     std::string decl, dist, norm;
     int counter = 0;
-    std::map<std::pair<size_t, std::string>, std::string> dmemo, pmemo;
-    Fused(const rm_node* nodes_, const DivisorSet* exact_) : nodes(nodes_), exact(exact_) {}
+    // A temporary of the distance pass and the region of the pass that computes it: 0 = every call, r > 0 =
+    // only when the r-th skippable block runs (bound_skip below).  The distance pass re-uses a temporary only
+    // where it is sure to have been computed; the normal's pass may use any (it runs only after a trip in
+    // which no block was skipped, see bound_skip).
+    struct Temp { std::string var; int region; };
+    std::map<std::pair<size_t, std::string>, Temp> dmemo, pmemo;
+    int region = 0, regions = 0;      // the block being emitted (0: none); blocks so far
+    int glata_depth = 0;              // smooth combinators above the node being emitted
+    bool in_norm = false;             // emitting the normal's pass
+    bool allow_skip = true;
+    Fused(const rm_node* nodes_, const DivisorSet* exact_) : nodes(nodes_), exact(exact_) {
+        if (const char* env = std::getenv("RM_BOUND_SKIP")) allow_skip = std::atoi(env) != 0;      // experiments only
+    }
+    bool usable(const Temp& t) const { return in_norm || t.region == 0 || t.region == region; }
 
     std::string new_f() { std::string v = "d" + std::to_string(counter++); decl += "    float " + v + ";\n"; return "k." + v; }
     std::string new_p() { std::string v = "p" + std::to_string(counter++); decl += "    P3 " + v + ";\n"; return "k." + v; }
@@ -125,7 +141,7 @@ struct Fused {
     std::string point(size_t i, const std::string& pv) {
         const auto key = std::make_pair(i, pv);
         auto it = pmemo.find(key);
-        if (it != pmemo.end()) return it->second;
+        if (it != pmemo.end() && usable(it->second)) return it->second.var;
         const rm_node& nd = nodes[i];
         const std::string q = new_p();
         std::string e;
@@ -141,27 +157,57 @@ struct Fused {
         }
         }
         dist += "    " + q + " = " + e + ";\n";
-        pmemo[key] = q;
+        pmemo[key] = Temp{q, in_norm ? 0 : region};
         return q;
     }
 
-    // operands of the min (want_min) or max chain that node i, negated or not, continues
-    void chain(size_t i, const std::string& pv, bool neg, bool want_min, std::vector<std::pair<std::string, bool>>& ops) {
+    // operands (node, negated) of the min (want_min) or max chain that node i, negated or not, continues
+    void chain(size_t i, bool neg, bool want_min, std::vector<std::pair<size_t, bool>>& ops) const {
         const rm_node& nd = nodes[i];
         const bool comb = nd.type == RM_TYPE_KUNIGAJO_2 || nd.type == RM_TYPE_KUNIGAJO_3 || nd.type == RM_TYPE_KUNIGAJO_4 ||
                           nd.type == RM_TYPE_KOMUNAJO_2 || nd.type == RM_TYPE_KOMUNAJO_3 || nd.type == RM_TYPE_KOMUNAJO_4;
-        if (nd.type == RM_TYPE_KOMPLEMENTO) { chain(kid(i, 0), pv, !neg, want_min, ops); return; }
+        if (nd.type == RM_TYPE_KOMPLEMENTO) { chain(kid(i, 0), !neg, want_min, ops); return; }
         if (comb && (is_min(nd.type) != neg) == want_min) {
-            for (int c = 0; c < node_arity(nd.type); ++c) chain(kid(i, c), pv, neg, want_min, ops);
+            for (int c = 0; c < node_arity(nd.type); ++c) chain(kid(i, c), neg, want_min, ops);
             return;
         }
-        ops.emplace_back(d(i, pv), neg);
+        ops.emplace_back(i, neg);
+    }
+
+    // An upper bound of -DIST(node i, p) that holds at every point, if the node is a solid under transforms
+    // only: -(|q| - r) <= r for a sphere; a box's distance is at least -min(b) (its value at the centre) when
+    // no half-extent is negative, a cylinder's at least -min(r, h) likewise.  The rounded arithmetic keeps the
+    // bound (|q| >= 0 and rounding is monotonic: RN(|q| - r) >= -r; the box's and the cylinder's terms likewise).
+    bool carve_bound(size_t i, float* bound) const {
+        for (;;) {
+            const rm_node& nd = nodes[i];
+            switch (nd.type) {
+            case RM_TYPE_MOVO: case RM_TYPE_SENFINA_RIPETO: case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY:
+            case RM_TYPE_ROTACIOZ: case RM_TYPE_ROTACIOQ:
+                i = kid(i, 0);
+                continue;
+            case RM_TYPE_SFERO:
+                *bound = nd.f[0];
+                return nd.f[0] == nd.f[0] && nd.f[0] < 1e30f;
+            case RM_TYPE_KUBO: {
+                const float m = std::min(nd.f[0], std::min(nd.f[1], nd.f[2]));
+                *bound = m;
+                return m >= 0.f && m < 1e30f;            // false for NaN
+            }
+            case RM_TYPE_CILINDRO: {
+                const float m = std::min(nd.f[0], nd.f[1]);
+                *bound = m;
+                return m >= 0.f && m < 1e30f;
+            }
+            default: return false;
+            }
+        }
     }
 
     std::string d(size_t i, const std::string& pv) {
         const auto key = std::make_pair(i, pv);
         auto it = dmemo.find(key);
-        if (it != dmemo.end()) return it->second;
+        if (it != dmemo.end() && usable(it->second)) return it->second.var;
         const rm_node& nd = nodes[i];
         std::string v;
         auto leaf = [&](const std::string& call) { v = new_f(); dist += "    " + v + " = " + call + ";\n"; };
@@ -182,7 +228,9 @@ struct Fused {
             v = d(kid(i, 0), point(i, pv));
             break;
         case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: {
+            ++glata_depth;
             const std::string a = d(kid(i, 0), pv), b = d(kid(i, 1), pv);
+            --glata_depth;
             leaf("glata(" + a + ", " + b + ", " + lit(nd.f[0]) + ", " + lit(divisor_reciprocal(exact, nd.f[0])) + ", " +
                  (nd.type == RM_TYPE_GLATA_KOMUNAJO_2 ? "true" : "false") + ")");
             break;
@@ -193,41 +241,82 @@ struct Fused {
             // (-min(a, b) = max(-a, -b)).  Emitted as v_min3 / v_max3 with the negations in the
             // instruction, written out: through the compiler each operand it cannot prove canonical
             // would cost an extra v_max x, x.
-            std::vector<std::pair<std::string, bool>> ops;
+            std::vector<std::pair<size_t, bool>> members;
             const bool mn = is_min(nd.type);
-            chain(i, pv, false, mn, ops);
+            chain(i, false, mn, members);
             const char* op3 = mn ? "v_min3_f32" : "v_max3_f32";
             const char* op2 = mn ? "v_min_f32_e64" : "v_max_f32_e64";
-            auto src = [&](size_t k, int arg) { return std::string(ops[k].second ? "-%" : "%") + std::to_string(arg); };
             v = new_f();
-            size_t at = 0;
-            std::string acc;                    // variable holding the running value, never negated
-            while (at < ops.size()) {
-                const size_t left = ops.size() - at;
-                std::string text, ins;
-                if (acc.empty() && left >= 3) {
-                    text = std::string(op3) + " %0, " + src(at, 1) + ", " + src(at + 1, 2) + ", " + src(at + 2, 3);
-                    ins = "\"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + "), \"v\"(" + ops[at + 2].first + ")";
-                    at += 3;
-                } else if (acc.empty()) {       // exactly two operands in all
-                    text = std::string(op2) + " %0, " + src(at, 1) + ", " + src(at + 1, 2);
-                    ins = "\"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + ")";
-                    at += 2;
-                } else if (left >= 2) {
-                    text = std::string(op3) + " %0, %1, " + src(at, 2) + ", " + src(at + 1, 3);
-                    ins = "\"v\"(" + acc + "), \"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + ")";
-                    at += 2;
-                } else {
-                    text = std::string(op2) + " %0, %1, " + src(at, 2);
-                    ins = "\"v\"(" + acc + "), \"v\"(" + ops[at].first + ")";
-                    at += 1;
+            // folds `ops` (temporary, negated) into v; `acc`: v already holds a running value
+            auto fold = [&](const std::vector<std::pair<std::string, bool>>& ops, bool acc_in, const std::string& pad) {
+                auto src = [&](size_t k, int arg) { return std::string(ops[k].second ? "-%" : "%") + std::to_string(arg); };
+                size_t at = 0;
+                std::string acc = acc_in ? v : std::string();          // variable holding the running value, never negated
+                while (at < ops.size()) {
+                    const size_t left = ops.size() - at;
+                    std::string text, ins;
+                    if (acc.empty() && left >= 3) {
+                        text = std::string(op3) + " %0, " + src(at, 1) + ", " + src(at + 1, 2) + ", " + src(at + 2, 3);
+                        ins = "\"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + "), \"v\"(" + ops[at + 2].first + ")";
+                        at += 3;
+                    } else if (acc.empty() && left == 2) {
+                        text = std::string(op2) + " %0, " + src(at, 1) + ", " + src(at + 1, 2);
+                        ins = "\"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + ")";
+                        at += 2;
+                    } else if (acc.empty()) {       // a single operand: a copy, negated or not
+                        dist += pad + v + " = " + (ops[at].second ? "-" : "") + ops[at].first + ";\n";
+                        acc = v;
+                        at += 1;
+                        continue;
+                    } else if (left >= 2) {
+                        text = std::string(op3) + " %0, %1, " + src(at, 2) + ", " + src(at + 1, 3);
+                        ins = "\"v\"(" + acc + "), \"v\"(" + ops[at].first + "), \"v\"(" + ops[at + 1].first + ")";
+                        at += 2;
+                    } else {
+                        text = std::string(op2) + " %0, %1, " + src(at, 2);
+                        ins = "\"v\"(" + acc + "), \"v\"(" + ops[at].first + ")";
+                        at += 1;
+                    }
+                    dist += pad + "asm(\"" + text + "\" : \"=v\"(" + v + ") : " + ins + ");\n";
+                    acc = v;
                 }
-                dist += "    asm(\"" + text + "\" : \"=v\"(" + v + ") : " + ins + ");\n";
-                acc = v;
+            };
+            // bound_skip: the carved-out solids of a komunajo (A minus B: max(A, -B)) are behind a test.  -B never
+            // exceeds its static bound (carve_bound), so where the max over the other members already exceeds
+            // every such bound for all marching lanes, max() returns that value bit for bit and the solids are
+            // not evaluated (chair.sce: a ray that is more than 60 units from the box skips both spheres, two
+            // of the three square roots of a step).  A skipped block leaves its temporaries stale.  The normal's
+            // pass reads them only for a lane whose root distance this chain decided and which is at a surface:
+            // this chain's value is then below RM_MIN_DIST in magnitude, so with a bound of at least RM_MIN_DIST
+            // the block ran.  That argument needs the root value to BE this chain's value (through min, max,
+            // komplemento and transforms); under a glata it is a blend, so no block is made there.
+            std::vector<std::pair<size_t, bool>> open, carved;
+            float bound = 0.f;
+            if (!mn && allow_skip && region == 0 && glata_depth == 0) {
+                for (const auto& m : members) {
+                    float b;
+                    if (m.second && carve_bound(m.first, &b)) { carved.push_back(m); bound = carved.size() == 1 ? b : std::max(bound, b); }
+                    else open.push_back(m);
+                }
+                if (open.empty() || carved.empty() || !(bound >= RM_MIN_DIST)) { open = members; carved.clear(); }
+            } else {
+                open = members;
+            }
+            std::vector<std::pair<std::string, bool>> ops;
+            for (const auto& m : open) ops.emplace_back(d(m.first, pv), m.second);
+            fold(ops, false, "    ");
+            if (!carved.empty()) {
+                dist += "    if (!SKIP || (__builtin_amdgcn_ballot_w64(!(" + v + " > " + lit(bound) + ")) & amask) != 0) {\n";
+                region = ++regions;
+                ops.clear();
+                for (const auto& m : carved) ops.emplace_back(d(m.first, pv), m.second);
+                fold(ops, true, "        ");
+                region = 0;
+                dist += "    }\n";
             }
         }
         }
-        dmemo[key] = v;
+        dmemo[key] = Temp{v, in_norm ? 0 : region};
         return v;
     }
 
@@ -236,7 +325,7 @@ struct Fused {
     // over its children, evaluated only by the lanes that take a normal
     std::string value(size_t i, const std::string& pv) {
         auto it = dmemo.find(std::make_pair(i, pv));
-        if (it != dmemo.end()) return it->second;
+        if (it != dmemo.end() && usable(it->second)) return it->second.var;
         const rm_node& nd = nodes[i];
         if (nd.type == RM_TYPE_KOMPLEMENTO) return "(-" + value(kid(i, 0), pv) + ")";
         const int na = node_arity(nd.type);
@@ -322,9 +411,14 @@ struct Fused {
 
     std::string source() {
         const std::string root = d(0, "E");
+        in_norm = true;
         n(0, "E", "N", 1);
+        // SKIP: the blocks of bound_skip may be skipped (amask: the lanes whose distance matters).  The march asks
+        // with SKIP = true; a caller that takes normals at points of its own choosing (known-answer hook) with false.
         return "struct SceneKeep {\n" + decl + "};\n"
-               "__device__ __forceinline__ float scene_dist_keep(P3 E, SceneKeep& k) {\n" + dist + "    return " + root + ";\n}\n"
+               "template <bool SKIP>\n"
+               "__device__ __forceinline__ float scene_dist_keep(P3 E, SceneKeep& k, unsigned long long amask) {\n" + dist +
+               "    (void)amask;\n    return " + root + ";\n}\n"
                "__device__ __forceinline__ P3 scene_norm_keep(P3 E, const SceneKeep& k) {\n    P3 N{0.f, 0.f, 0.f};\n" + norm +
                "    (void)E; (void)k;\n    return N;\n}\n";
     }
@@ -443,6 +537,7 @@ struct JitScene {
     struct Keep {};
     __device__ __forceinline__ void init(const RenderParams&) {}
     __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, bool active, Keep& k) { return dist_keep(p, s, active, k); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep&) { return n0(p); }
 };
 }  // namespace rm
@@ -456,7 +551,10 @@ struct JitScene {
     struct Scratch {};
     typedef SceneKeep Keep;
     __device__ __forceinline__ void init(const RenderParams&) {}
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool, Keep& k) { return scene_dist_keep(p, k); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep& k) {
+        return scene_dist_keep<true>(p, k, __builtin_amdgcn_ballot_w64(active));
+    }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch&, bool, Keep& k) { return scene_dist_keep<false>(p, k, ~0ull); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep& k) { return scene_norm_keep(p, k); }
 };
 }  // namespace rm
@@ -700,6 +798,7 @@ struct JitScene {
     }
     struct Keep {};
     __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, bool active, Keep& k) { return dist_keep(p, s, active, k); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return walk_norm(tree, 0, p, st); }
 };
 }  // namespace rm
@@ -762,6 +861,7 @@ struct JitScene {
     struct Keep {};
     __device__ __forceinline__ float dist_keep(P3 p, Scratch& st, bool active, Keep&) { return )") +
          (grouped ? "scene_program(p, active, st.first)" : "scene_program(p, active)") + R"(; }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, bool active, Keep& k) { return dist_keep(p, s, active, k); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return scene_norm(p, st.first); }
 };
 }  // namespace rm
