@@ -374,7 +374,8 @@ struct InterpScene {
     // What the normal may re-use of the distance just evaluated at the same point: nothing here
     // (the generated scenes of jit.cpp keep their transformed points and child distances).
     struct Keep {};
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch& st, bool active, Keep&) { return dist(p, st, active); }
+    // amask: the lanes whose distance matters (a wave-level mask, as the march loop keeps it)
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch& st, unsigned long long amask, Keep&) { return dist(p, st, rm_lane_of_mask(amask)); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return norm(p, st); }
 };
 

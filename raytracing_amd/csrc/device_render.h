@@ -235,11 +235,41 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         uint32_t next_check = boost_age < 1023 ? boost_age + 1 : 1024;
         auto lanes = [](unsigned long long m) { return rm_lane_of_mask(m); };   // this lane's bit of a mask
 
-        for (;;) {
-            // One compare per trip for the two things that happen rarely: a tile that runs long goes
-            // first on its SIMD from trip boost_age + 1 on (the long tiles set the length of the frame),
-            // and the watchdog looks at the clock every 1024 trips.
-            if (++trips == next_check) {
+        // The scalar unit is shared by the four SIMDs of a CU and takes 4.3 cycles per instruction of a SIMD
+        // (tools/microbench/valu_peak.hip, "mix"): a trip of ~70 vector instructions may hold ~35 scalar ones
+        // before they, not the vector ones, set its length.  So the common trip - primary lanes only, none at a
+        // surface, nothing due - has a tail of its own with a dozen scalar instructions, and everything else
+        // (shadow lanes, normals, the step cap, priority and watchdog) goes through the general tail.
+        // `due`: the trip at which the general tail must run whatever the lanes do.
+        uint32_t due = next_check < (uint32_t)RM_PRIMARY_STEPS ? next_check : (uint32_t)RM_PRIMARY_STEPS;
+        while (m_p | m_s) {
+            P3 at;
+            typename Scene::Keep keep;
+            unsigned long long near;
+            for (;;) {
+                ++trips;
+                // DIST(root, pos) for the whole wave (:627 and :661 share this)
+                at = pos;
+                cd = scene.dist_keep(at, scratch, m_p | m_s, keep);       // every lane: nothing reads a resting lane's value
+                // lanes at a surface: cd < RM_MIN_DIST on the primary march (:629), 8 * cd < RM_MIN_DIST on the shadow march (:662)
+                near = __builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p;
+                if (near | m_s) break;
+                asm volatile("" ::: "memory");             // two scalar branches: merged, the compiler evaluates the pair as lane masks
+                if (trips >= due) break;
+                // ---- the common tail: every marching lane is a primary lane in free space (:707-714)
+                if (lanes(m_p)) {
+                    pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
+                    t += cd;
+                }
+                m_p &= ~__builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST);     // a resting lane's stale t clears a bit that is clear
+                if (m_p == 0) break;
+            }
+            if ((m_p | m_s) == 0) break;
+
+            // ---- the general tail
+            // a tile that runs long goes first on its SIMD from trip boost_age + 1 on (the long tiles set the
+            // length of the frame), and the watchdog looks at the clock every 1024 trips
+            if (trips >= next_check) {
                 if (boost_on && level < RM_PRIO_LEVELS && trips > tier(level)) {
                     do ++level; while (level < RM_PRIO_LEVELS && trips > tier(level));
                     if (level == 1) __builtin_amdgcn_s_setprio(1);
@@ -249,18 +279,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 if (__builtin_amdgcn_s_memtime() - t_enter > kernarg_params()->watchdog) { expired = true; break; }
                 next_check = trips + 1024;
                 if (boost_on && level < RM_PRIO_LEVELS && tier(level) >= trips && tier(level) - trips < 1024) next_check = tier(level) + 1;
+                due = next_check < (uint32_t)RM_PRIMARY_STEPS ? next_check : (uint32_t)RM_PRIMARY_STEPS;
+                if (trips >= (uint32_t)RM_PRIMARY_STEPS) due = trips + 1;      // past the primary cap every trip takes this tail (m_p is empty by then)
+                next_check = uniform(next_check); due = uniform(due);          // (the compiler would keep them in vector registers)
             }
-
-            const unsigned long long marching = m_p | m_s;
-            if (marching == 0) break;
-            ++st_evals;
-            // DIST(root, pos) for the whole wave (:627 and :661 share this)
-            const P3 at = pos;
-            typename Scene::Keep keep;
-            cd = scene.dist_keep(at, scratch, lanes(marching), keep);     // every lane: nothing reads a resting lane's value
-
-            // lanes at a surface: cd < RM_MIN_DIST on the primary march (:629), 8 * cd < RM_MIN_DIST on the shadow march (:662)
-            unsigned long long near = __builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p;
             if (m_s) near |= __builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s;
 
             // ---- rare: some lane is at a surface.  It takes its normal in this trip, at the point the distance
@@ -313,25 +335,29 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             const unsigned long long go_s = m_s & ~occluded;
             unsigned long long left_s = 0;
             if (go_s) {
-                bool ends = false;
-                if (lanes(go_s)) {
-                    // shadow = min(shadow, (128*cd)/t).  The quotient matters only when it is below `shadow`, and
-                    // most steps it is not: n > shadow*t, by a margin that covers the product's rounding, means
-                    // n/t > shadow in exact arithmetic, so the rounded quotient is >= shadow and min() keeps
-                    // `shadow` bit for bit.  Only the other lanes pay for the division (12 instructions).
-                    const float n = RM_HARDNESS * cd, st = shadow * t;
-                    if (!(n > st + fabsf(st) * 4.8e-7f)) {
+                // shadow = min(shadow, (128*cd)/t).  The quotient matters only when it is below `shadow`, and
+                // most steps it is not: n > shadow*t, by a margin that covers the product's rounding, means
+                // n/t > shadow in exact arithmetic, so the rounded quotient is >= shadow and min() keeps
+                // `shadow` bit for bit.  The division (12 instructions) runs only in a trip in which some
+                // shadow lane needs it, and then for all of them (for the others min() changes nothing):
+                // one scalar branch, no divergence.
+                const float n = RM_HARDNESS * cd, st = shadow * t;
+                if (__builtin_amdgcn_ballot_w64(!(n > st + fabsf(st) * 4.8e-7f)) & go_s) {
+                    if (lanes(go_s)) {
                         float ns = n;
-                        asm volatile("; shadow quotient" : "+v"(ns));           // a branch, not a select over a speculated division
+                        asm volatile("; shadow quotient" : "+v"(ns));           // keeps the division behind the branch
                         shadow = min2(shadow, ns / t);
                     }
-                    if (shadow < 0.01f) ends = true;
-                    else {
-                        pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
-                        t += cd;
-                        ends = t >= RM_MAX_DIST || trips >= deadline;
-                    }
                 }
+                // (:680-690) a lane whose shadow fell below .01 stops before the step, one that marches past
+                // RM_MAX_DIST or has made RM_SHADOW_STEPS steps after it: either way it is shaded now and its
+                // position is dead, so every shadow lane takes the step and the three ends are one mask
+                bool ends = shadow < 0.01f;
+                if (lanes(go_s)) {
+                    pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
+                    t += cd;
+                }
+                ends = ends || t >= RM_MAX_DIST || trips >= deadline;
                 left_s = __builtin_amdgcn_ballot_w64(ends) & go_s;
             }
 
@@ -346,6 +372,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             m_p = go_p & ~left_p;
             m_s = (go_s & ~left_s) | turn;
         }
+        st_evals += trips;
         if (level) __builtin_amdgcn_s_setprio(0);
         if (expired) break;
 

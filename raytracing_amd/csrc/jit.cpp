@@ -72,10 +72,11 @@ rm_eval_points_jit(const rm::RenderParams prm, const float* __restrict__ xyz, ui
     rm::P3 p{0.f, 0.f, 0.f};
     if (live) p = rm::P3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     rm::JitScene::Keep keep;
-    const float d = scene.dist_keep(p, scratch, live, keep);          // wave-uniform code: every lane runs it
+    const unsigned long long amask = __builtin_amdgcn_ballot_w64(live);
+    const float d = scene.dist_keep(p, scratch, amask, keep);         // wave-uniform code: every lane runs it
     // The march takes a normal only where the distance says a surface is near; this hook takes one at every point,
     // so its distance pass may not skip what the march's may (Fused::bound_skip)
-    if (norm_out) (void)scene.dist_keep_all(p, scratch, live, keep);
+    if (norm_out) (void)scene.dist_keep_all(p, scratch, amask, keep);
     if (live) {
         dist_out[i] = d;
         if (norm_out) {
@@ -536,8 +537,8 @@ struct JitScene {
     struct Scratch {};
     struct Keep {};
     __device__ __forceinline__ void init(const RenderParams&) {}
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
-    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, bool active, Keep& k) { return dist_keep(p, s, active, k); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, unsigned long long amask, Keep&) { return scene_program(p, amask); }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, unsigned long long amask, Keep& k) { return dist_keep(p, s, amask, k); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep&) { return n0(p); }
 };
 }  // namespace rm
@@ -551,10 +552,8 @@ struct JitScene {
     struct Scratch {};
     typedef SceneKeep Keep;
     __device__ __forceinline__ void init(const RenderParams&) {}
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep& k) {
-        return scene_dist_keep<true>(p, k, __builtin_amdgcn_ballot_w64(active));
-    }
-    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch&, bool, Keep& k) { return scene_dist_keep<false>(p, k, ~0ull); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, unsigned long long amask, Keep& k) { return scene_dist_keep<true>(p, k, amask); }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch&, unsigned long long, Keep& k) { return scene_dist_keep<false>(p, k, ~0ull); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep& k) { return scene_norm_keep(p, k); }
 };
 }  // namespace rm
@@ -722,11 +721,11 @@ UnionGroups union_groups(const std::vector<Slot>& prog) {
 std::string grouped_function(const std::vector<Slot>& program, const UnionGroups& u, bool select,
                              const std::vector<int32_t>* slot_node, const std::vector<uint32_t>* ranks) {
     std::string s = select ? "__device__ __forceinline__ uint32_t scene_pick(P3 E, uint32_t first, P3& F, float& Aout) {\n"
-                           : "__device__ __forceinline__ float scene_program(P3 E, bool active, uint32_t& first) {\n";
+                           : "__device__ __forceinline__ float scene_program(P3 E, unsigned long long amask, uint32_t& first) {\n";
     if (select) s += "    const bool active = true;     // called by the lanes that need a normal: the others are masked off\n    F = E;\n";
     else s += "    P3 F = E;\n";
     s += "    P3 P = E; float A = __builtin_inff(), tx = 0.f, ty = 0.f;\n";
-    s += "    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);\n";
+    if (select) s += "    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);\n";
     if (select) s += "    uint32_t best = 0u, brank = 0u;\n";
     else s += "    uint32_t bestg = first;\n";
     bool a_inf = false;
@@ -754,16 +753,15 @@ std::string grouped_function(const std::vector<Slot>& program, const UnionGroups
         s += "    (void)tx; (void)ty; (void)P; (void)brank;\n    Aout = A;\n    return best;\n}\n";
     } else {
         s += "    // the next call starts with the group that holds the minimum of the first marching lane\n";
-        s += "    first = (uint32_t)__builtin_amdgcn_readlane((int)bestg, (int)__builtin_ctzll(amask));\n";
+        s += "    if (amask) first = (uint32_t)__builtin_amdgcn_readlane((int)bestg, (int)__builtin_ctzll(amask));\n";
         s += "    (void)tx; (void)ty; (void)P;\n    return A;\n}\n";
     }
     return s;
 }
 
 std::string program_function(const std::vector<Slot>& program, uint32_t value_slots) {
-    std::string s = "__device__ __forceinline__ float scene_program(P3 E, bool active) {\n";
+    std::string s = "__device__ __forceinline__ float scene_program(P3 E, unsigned long long amask) {\n";
     s += "    P3 F = E, P = E; float A = __builtin_inff(), B = 0.f, tx = 0.f, ty = 0.f;\n";
-    s += "    const unsigned long long amask = __builtin_amdgcn_ballot_w64(active);\n";
     if (value_slots) {
         s += "    float";
         for (uint32_t k = 0; k < value_slots; ++k) s += std::string(k ? "," : "") + " s" + std::to_string(k) + " = 0.f";
@@ -797,8 +795,8 @@ struct JitScene {
         stage_tree(prm.tree, prm.n_nodes, lds);
     }
     struct Keep {};
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, bool active, Keep&) { return scene_program(p, active); }
-    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, bool active, Keep& k) { return dist_keep(p, s, active, k); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, unsigned long long amask, Keep&) { return scene_program(p, amask); }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, unsigned long long amask, Keep& k) { return dist_keep(p, s, amask, k); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return walk_norm(tree, 0, p, st); }
 };
 }  // namespace rm
@@ -859,9 +857,9 @@ struct JitScene {
     struct Scratch { uint32_t first = 0; };      // the group to visit first (wave-uniform)
     __device__ __forceinline__ void init(const RenderParams&) {}
     struct Keep {};
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch& st, bool active, Keep&) { return )") +
-         (grouped ? "scene_program(p, active, st.first)" : "scene_program(p, active)") + R"(; }
-    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, bool active, Keep& k) { return dist_keep(p, s, active, k); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch& st, unsigned long long amask, Keep&) { return )") +
+         (grouped ? "scene_program(p, amask, st.first)" : "scene_program(p, amask)") + R"(; }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, unsigned long long amask, Keep& k) { return dist_keep(p, s, amask, k); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch& st, const Keep&) { return scene_norm(p, st.first); }
 };
 }  // namespace rm

@@ -108,6 +108,50 @@ GEN(g_mul_lit, T_MUL_LIT) GEN(g_add_sgpr, T_ADD_SGPR) GEN(g_fmac, T_FMAC) GEN(g_
 GEN(g_med3, T_MED3) GEN(g_cmp32, T_CMP32) GEN(g_cnd32, T_CND32) GEN(g_rsq, T_RSQ) GEN(g_floor, T_FLOOR)
 GEN(g_and, T_AND) GEN(g_addabs, T_ADDABS) GEN(g_sub, T_SUBNEG) GEN(g_mov, T_MOV)
 
+// scalar instructions alone, and interleaved with vector ones (K_V vector additions per scalar one): does a wave's
+// scalar work hide under the vector work of the other waves of its SIMD?  256 scalar + 256 * K_V vector per body.
+template <int K_V, int K_S>
+__global__ void __launch_bounds__(256) mix(float* out, float seed, unsigned long long* cyc, unsigned useed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    const float c = seed * 0.5f;
+    unsigned s0 = useed, s1 = useed + 1, s2 = useed + 2, s3 = useed + 3;
+    for (int i = 0; i < N_ITER; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (K_V >= 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a0) : "v"(c));
+            if (K_S >= 1) asm volatile("s_add_u32 %0, %0, 3" : "+s"(s0) : : "scc");
+            if (K_V >= 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a1) : "v"(c));
+            if (K_S >= 2) asm volatile("s_and_b32 %0, %0, 0xffffff" : "+s"(s1) : : "scc");
+            if (K_V >= 3) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a2) : "v"(c));
+            if (K_S >= 3) asm volatile("s_add_u32 %0, %0, 5" : "+s"(s2) : : "scc");
+            if (K_V >= 4) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a3) : "v"(c));
+            if (K_S >= 4) asm volatile("s_or_b32 %0, %0, 1" : "+s"(s3) : : "scc");
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3;
+    if (threadIdx.x == 0) out[blockIdx.x * 256] += (float)(s0 + s1 + s2 + s3);
+    if (threadIdx.x == 0) cyc[blockIdx.x] = 0;
+}
+template <int K_V, int K_S>
+void run_mix(int waves_per_simd, float* d_out, unsigned long long* d_cyc) {
+    const int blocks = 256 * waves_per_simd;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((mix<K_V, K_S>), dim3(blocks), dim3(256), 0, 0, d_out, 1.0f, d_cyc, 7u);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((mix<K_V, K_S>), dim3(blocks), dim3(256), 0, 0, d_out, 1.0f, d_cyc, 7u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double per_wave = 16.0 * N_ITER;                       // bodies per wave
+    const double waves = blocks * 4.0;
+    // cycles per SIMD at 2.4 GHz per body (K_V vector + K_S scalar instructions of one wave)
+    const double simd_cycles = ms * 1e-3 * 2.4e9;
+    printf("mix %d vector + %d scalar per body, waves/SIMD %d: %8.3f ms  -> %.2f SIMD-cycles (at 2.4 GHz) per body per wave\n",
+           K_V, K_S, waves_per_simd, ms, simd_cycles / (per_wave * waves_per_simd));
+    (void)waves;
+}
+
 typedef void (*kern_t)(float*, float, unsigned long long*);
 void run_gen(const char* name, kern_t kfn, int waves_per_simd, float* d_out, unsigned long long* d_cyc) {
     const int blocks = 256 * waves_per_simd;
@@ -148,6 +192,13 @@ void run(const char* name, int waves_per_simd, float* d_out, unsigned long long*
 int main(int argc, char** argv) {
     float* d_out; unsigned long long* d_cyc;
     hipMalloc(&d_out, 256 * 8 * 256 * 4); hipMalloc(&d_cyc, 256 * 8 * 8);
+    if (argc > 1 && argv[1][0] == 's') {     // scalar / vector mixes
+        for (int w : {4, 8}) {
+            run_mix<4, 0>(w, d_out, d_cyc); run_mix<0, 4>(w, d_out, d_cyc); run_mix<4, 1>(w, d_out, d_cyc);
+            run_mix<4, 2>(w, d_out, d_cyc); run_mix<4, 4>(w, d_out, d_cyc); run_mix<2, 4>(w, d_out, d_cyc);
+        }
+        return 0;
+    }
     if (argc > 1) {          // round 2: the instruction kinds of the march loop's tests and selects, 8 waves per SIMD
         const int w = 8;
         run_gen("v_add_f32 (ref)", g_add_sgpr, w, d_out, d_cyc);

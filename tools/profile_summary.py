@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""profile_summary.py TAG [note]: turn what tools/profile_round.sh TAG left under gpurun_out/ into
-profiles/TAG_chair4k.txt (kernel trace, bench line, counters per launch, derived figures) and
-profiles/TAG_counters.json (read by bench.py for roofline.traffic)."""
+"""profile_summary.py TAG [WORKLOAD] [note] [--out DIR]: turn what tools/profile_round.sh TAG WORKLOAD left under
+gpurun_out/ into DIR/TAG.txt (kernel trace, bench line, counters per launch, derived figures),
+DIR/TAG_counters.json (read by bench.py for roofline.traffic of that workload) and DIR/TAG_bench.json.
+DIR defaults to profiles/."""
 import csv
 import glob
 import json
@@ -10,14 +11,25 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
-note = sys.argv[2] if len(sys.argv) > 2 else ""
+sys.path.insert(0, ROOT)
+from bench import WORKLOADS
+
+argv = sys.argv[1:]
+out_dir = os.path.join(ROOT, "profiles")
+if "--out" in argv:
+    k = argv.index("--out")
+    out_dir = os.path.join(ROOT, argv[k + 1])
+    del argv[k:k + 2]
+tag = argv[0]
+workload = argv[1] if len(argv) > 1 else "chair_4k"
+note = argv[2] if len(argv) > 2 else ""
+scene, W, H = WORKLOADS[workload]
 G = os.path.join(ROOT, "gpurun_out")
 KERNEL = "rm_render_jit"
 PMC_WARM_LAUNCHES, PMC_LAUNCHES = 1, 3      # the counter passes run --steps 24 --warmup 8 at 8 frames per launch
 
-lines = ["# %s: chair.sce 3840x2160, MI355X, one context, launches of 8 frames back to back; all figures per launch%s" % (tag, (" -- " + note) if note else ""),
-         "# command per pass: rocprofv3 [--kernel-trace --stats | --pmc <counters> --kernel-trace] -- python3 bench.py --steps K --warmup W --no-cpu-baseline",
+lines = ["# %s: %s (%s.sce %dx%d), MI355X, one context, launches of 8 frames back to back; all figures per launch%s" % (tag, workload, scene, W, H, (" -- " + note) if note else ""),
+         "# command per pass: rocprofv3 [--kernel-trace --stats | --pmc <counters> --kernel-trace] -- python3 bench.py --workload %s --steps K --warmup W --no-cpu-baseline --no-single-frame" % workload,
          "# (tools/profile_round.sh, summarised by tools/profile_summary.py; every counter pass is a run of its own)", ""]
 
 # ---- kernel trace
@@ -52,7 +64,7 @@ for path in sorted(glob.glob(os.path.join(G, tag + "_pmc_*", "**", "*counter_col
         per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
         per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     for name, by_dispatch in per.items():
-        vals = [v for _, v in sorted(by_dispatch.items())][PMC_WARM_LAUNCHES:PMC_WARM_LAUNCHES + PMC_LAUNCHES]
+        vals = [v for _, v in sorted(by_dispatch.items())][-PMC_LAUNCHES:]        # the timed launches are the last ones
         counters[name] = sum(vals) / len(vals)
 lines.append("## counters, mean per launch of %s over the timed launches (sum over the chip)" % KERNEL)
 for name, v in counters.items():
@@ -62,7 +74,7 @@ lines.append("")
 # ---- derived
 rec = json.loads(bench_line)
 fpl = rec["config"].get("frames_per_launch", 1)
-rays = 3840 * 2160 * fpl                      # per launch
+rays = W * H * fpl                            # per launch
 lines.append("## derived")
 if "GRBM_GUI_ACTIVE" in counters:
     cyc = counters["GRBM_GUI_ACTIVE"] / 8
@@ -74,8 +86,9 @@ if "GRBM_GUI_ACTIVE" in counters:
     if "SQ_ACTIVE_INST_VALU" in counters:
         lines.append("SQ_ACTIVE_INST_VALU per SIMD-cycle                           %10.3f" % (counters["SQ_ACTIVE_INST_VALU"] / simd_cycles))
 if "SQ_INSTS_VALU" in counters:
-    lines.append("lane-level VALU instructions per ray                         %10.0f  (algorithmic FLOP per ray: %.0f)"
-                 % (counters["SQ_INSTS_VALU"] * 64 / rays, rec["roofline"]["algorithmic_flops_per_ray"]))
+    alg = rec.get("roofline", {}).get("algorithmic_flops_per_ray")
+    lines.append("lane-level VALU instructions per ray                         %10.0f  (algorithmic FLOP per ray: %s)"
+                 % (counters["SQ_INSTS_VALU"] * 64 / rays, "%.0f" % alg if alg else "not counted for this workload"))
     if "SQ_INSTS_SALU" in counters:
         lines.append("SALU / VALU instructions                                     %10.2f" % (counters["SQ_INSTS_SALU"] / counters["SQ_INSTS_VALU"]))
 hbm = None
@@ -88,13 +101,14 @@ if "WRITE_SIZE" in counters and "FETCH_SIZE" in counters:
 if avg_us is not None:
     lines.append("average kernel duration in the trace %.1f us; bench.py's own HIP-event average %.1f us" % (avg_us, rec["kernel_ms"] * 1e3))
 
-out_txt = os.path.join(ROOT, "profiles", tag + "_chair4k.txt")
+os.makedirs(out_dir, exist_ok=True)
+out_txt = os.path.join(out_dir, tag + ".txt")
 with open(out_txt, "w") as f:
     f.write("\n".join(lines) + "\n")
-with open(os.path.join(ROOT, "profiles", tag + "_counters.json"), "w") as f:
-    json.dump({"workload": "chair_4k", "hbm_bytes_per_launch": hbm,
-               "source": "profiles/%s_chair4k.txt (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)" % tag,
+with open(os.path.join(out_dir, tag + "_counters.json"), "w") as f:
+    json.dump({"workload": workload, "frames_per_launch": fpl, "hbm_bytes_per_launch": hbm,
+               "source": "profiles/%s.txt (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)" % tag,
                "counters": counters}, f, indent=1)
-with open(os.path.join(ROOT, "profiles", tag + "_bench_chair4k.json"), "w") as f:
+with open(os.path.join(out_dir, tag + "_bench.json"), "w") as f:
     f.write(bench_line + "\n")
 print(open(out_txt).read())
