@@ -263,9 +263,11 @@ int rm_set_boost_age(rm_ctx* ctx, unsigned trips);
  * (default), 1 = per-lane tree walker (diagnostic; identical results). */
 int rm_set_evaluator(rm_ctx* ctx, int which);
 
-/* Diagnostics: render one frame and return, per (persistent) wavefront, 4
- * dwords: march loop trips, normal passes, shader cycles in the kernel, cycles
- * in normal passes.  With host_out NULL only *n_waves is set. */
+/* Diagnostics: render one launch and return, per (persistent) wavefront, 8
+ * dwords: march loop trips, normal passes, clock ticks in the kernel, ticks in
+ * normal passes, the low words of the clock (s_memtime, 100 MHz) when the
+ * wavefront started and when it left, tiles rendered, trips of its longest tile.
+ * With host_out NULL only *n_waves is set. */
 int rm_debug_wave_stats(rm_ctx* ctx, uint32_t* host_out, size_t cap_waves, size_t* n_waves);
 
 /* Diagnostics: the persistent wavefronts' watchdog, in s_memtime ticks (0 restores

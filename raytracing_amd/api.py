@@ -324,10 +324,10 @@ class Raymarching:
         return p.value, pitch.value
 
     def wave_stats(self):
-        """[waves, 4] uint32: loop trips, normal passes, cycles, cycles in normal passes."""
+        """[waves, 8] uint32: loop trips, normal passes, ticks, ticks in normal passes, start, end (clock low words), tiles, longest tile's trips."""
         n = C.c_size_t(0)
         _check(lib().rm_debug_wave_stats(self._ctx, None, 0, C.byref(n)), "rm_debug_wave_stats")
-        out = np.zeros((n.value, 4), dtype=np.uint32)
+        out = np.zeros((n.value, 8), dtype=np.uint32)
         _check(lib().rm_debug_wave_stats(self._ctx, _ptr(out), n.value, C.byref(n)), "rm_debug_wave_stats")
         return out
 

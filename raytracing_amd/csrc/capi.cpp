@@ -781,10 +781,10 @@ int rm_debug_wave_stats(rm_ctx* c, uint32_t* host_out, size_t cap_waves, size_t*
     if (c->local_rows == 0) return RM_OK;
     HIP_TRY(hipSetDevice(c->device));
     uint32_t* d = nullptr;
-    HIP_TRY(hipMalloc(&d, waves * 16));
-    hipError_t e = hipMemsetAsync(d, 0, waves * 16, c->stream);
+    HIP_TRY(hipMalloc(&d, waves * 32));
+    hipError_t e = hipMemsetAsync(d, 0, waves * 32, c->stream);
     if (e == hipSuccess) e = static_cast<hipError_t>(launch_frame(c, d, nullptr));
-    if (e == hipSuccess) e = hipMemcpyAsync(host_out, d, waves * 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_out, d, waves * 32, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = fetch_status(c);
     hipError_t s2 = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = s2;

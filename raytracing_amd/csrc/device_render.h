@@ -99,7 +99,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // counters' throughput is what binds (measured on chair 4K: 0.335 -> 0.284 ms per frame at 8 frames
     // per launch); a single frame is as long as its longest tile plus its share of the chip, and gains nothing
     // from either (kernel_params.h RM_SINGLE_CHUNK).
-    const bool merged = prm.nframes > 1;
+    const bool merged = RM_MERGE_ALWAYS || prm.nframes > 1;
     const uint32_t pull_chunk = merged ? RM_QUEUE_CHUNK : RM_SINGLE_CHUNK;
     uint32_t a_cursor = 0, a_head = home, a_total = 0, a_ticket = 0, a_run = 1, a_pos = 0;   // a_cursor: heads tried so far
     uint32_t a_cum[RM_COST_BUCKETS];                                   // running list lengths of a_head
@@ -135,7 +135,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         else a_ticket = bump(RM_SET_PULL(a_head), a_run);
     };
     // stage S: a tile id on its way (list entry), or already known (natural order)
-    uint32_t s_val = 0;
+    uint32_t s_val = 0, s_bucket = RM_COST_BUCKETS - 1;      // s_bucket: the cost bucket the previous launch filed the tile under
     bool s_valid = false;
     auto stage_s = [&]() {
         s_valid = false;
@@ -150,6 +150,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     KernargParams* kp = kernarg_params();
                     const uint32_t* list = kp->lists_prev + (size_t)(a_head * RM_COST_BUCKETS + b) * kp->list_cap;
                     s_val = __builtin_nontemporal_load(list + (c - base));
+                    s_bucket = a_head < RM_QUEUE_HEADS ? b : RM_COST_BUCKETS - 1;
                 } else {
                     s_val = a_head + RM_QUEUE_HEADS * c;
                 }
@@ -170,10 +171,11 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     stage_s();
 
     // optional per-wave diagnostics (rm_debug_wave_stats): trips, normal passes, cycles
-    uint32_t st_evals = 0, st_norms = 0, st_norm_cycles = 0;
+    uint32_t st_evals = 0, st_norms = 0, st_norm_cycles = 0, st_longest = 0;
     uint32_t r_base = 0, r_left = 0;         // places this wave holds in its head's cheap list (filing, below)
     uint32_t tiles_done = 0;                 // tiles this wave rendered to the end (RM_STATUS_COUNTERS)
     const uint64_t st_t0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t st_r0 = prm.wave_stats ? __builtin_amdgcn_s_memrealtime() : 0;        // the 100 MHz clock all XCDs share
 
     // Safety net for the persistent loop: every wave leaves after prm.watchdog clock ticks (2^36, about
     // ten minutes of s_memtime, unless a test lowered it) whatever state it is in, so a defect in the
@@ -185,6 +187,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     while (s_valid && !expired) {
         // ---- the next tile
         const uint32_t tile_id = uniform(s_val);
+        const uint32_t tile_bucket = s_bucket;
         stage_s();
         if (tile_id >= ntiles) continue;             // cannot happen with a sound list; never index past the image
         uint32_t frame = 0, tile = tile_id;
@@ -229,6 +232,12 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // four interleaved sweeps (tools/prio_probe.py) against one step and against every long tile
         // straight at priority 3: chair 4K 0.286 / 0.284 -> 0.276 ms per frame, infinity 0.894 / 0.875 -> 0.821.
         uint32_t level = 0;
+#if RM_PRIO_HISTORY
+        // a tile the previous launch found long starts where it would have risen to: its first trips count as much as its last
+        if (ordered && tile_bucket < 2) { level = 3 - tile_bucket; if (level == 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+#else
+        (void)tile_bucket;
+#endif
         const uint32_t boost_age = tp->boost_age;
         const bool boost_on = boost_age < (1u << 24);
         auto tier = [&](uint32_t k) { return k == 0 ? boost_age : k == 1 ? RM_PRIO_STEP2 * boost_age : RM_PRIO_STEP3 * boost_age; };
@@ -240,29 +249,63 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // before they, not the vector ones, set its length.  So the common trip - primary lanes only, none at a
         // surface, nothing due - has a tail of its own with a dozen scalar instructions, and everything else
         // (shadow lanes, normals, the step cap, priority and watchdog) goes through the general tail.
-        // `due`: the trip at which the general tail must run whatever the lanes do.
+        // `due`: the trip at which the general tail must run whatever the lanes do (next_check; for primary
+        // lanes also the step cap of :626).
         uint32_t due = next_check < (uint32_t)RM_PRIMARY_STEPS ? next_check : (uint32_t)RM_PRIMARY_STEPS;
         while (m_p | m_s) {
             P3 at;
             typename Scene::Keep keep;
-            unsigned long long near;
+            // The trips of a tile whose marching lanes are all in one phase and none at a surface.  A trip that
+            // is anything else leaves this loop evaluated (trips, at, cd, keep) and the general tail finishes it.
             for (;;) {
                 ++trips;
                 // DIST(root, pos) for the whole wave (:627 and :661 share this)
                 at = pos;
                 cd = scene.dist_keep(at, scratch, m_p | m_s, keep);       // every lane: nothing reads a resting lane's value
-                // lanes at a surface: cd < RM_MIN_DIST on the primary march (:629), 8 * cd < RM_MIN_DIST on the shadow march (:662)
-                near = __builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p;
-                if (near | m_s) break;
-                asm volatile("" ::: "memory");             // two scalar branches: merged, the compiler evaluates the pair as lane masks
-                if (trips >= due) break;
-                // ---- the common tail: every marching lane is a primary lane in free space (:707-714)
-                if (lanes(m_p)) {
-                    pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
-                    t += cd;
+                if (m_s == 0) {
+                    // ---- primary lanes only (:707-714); at a surface: cd < RM_MIN_DIST (:629)
+                    if (__builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p) break;
+                    asm volatile("" ::: "memory");         // two scalar branches: merged, the compiler evaluates the pair as lane masks
+                    if (trips >= due) break;
+                    if (lanes(m_p)) {
+                        pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
+                        t += cd;
+                    }
+                    m_p &= ~__builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST);     // a resting lane's stale t clears a bit that is clear
+                    if (m_p == 0) break;
+                } else if (m_p == 0) {
+                    // ---- shadow lanes only (:679-690); at a surface: 8 * cd < RM_MIN_DIST (:662)
+                    if (__builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s) break;
+                    asm volatile("" ::: "memory");
+                    if (trips >= next_check) break;
+                    // shadow = min(shadow, (128*cd)/t), the division only in a trip in which it can lower some
+                    // lane's shadow, and then for all of them (see the general tail)
+                    const float n = RM_HARDNESS * cd, st = shadow * t;
+                    if (__builtin_amdgcn_ballot_w64(!(n > st + fabsf(st) * 4.8e-7f)) & m_s) {
+                        if (lanes(m_s)) {
+                            float ns = n;
+                            asm volatile("; shadow quotient" : "+v"(ns));       // keeps the division behind the branch
+                            shadow = min2(shadow, ns / t);
+                        }
+                    }
+                    bool ends = shadow < 0.01f;
+                    if (lanes(m_s)) {
+                        pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
+                        t += cd;
+                    }
+                    ends = ends || t >= RM_MAX_DIST || trips >= deadline;
+                    const unsigned long long left = __builtin_amdgcn_ballot_w64(ends) & m_s;
+                    if (left) {                                                        // :693-701
+                        if (lanes(left)) {
+                            float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
+                            shaded = 0x100u | to_u8(lum);
+                        }
+                        m_s &= ~left;
+                        if (m_s == 0) break;
+                    }
+                } else {
+                    break;
                 }
-                m_p &= ~__builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST);     // a resting lane's stale t clears a bit that is clear
-                if (m_p == 0) break;
             }
             if ((m_p | m_s) == 0) break;
 
@@ -283,6 +326,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 if (trips >= (uint32_t)RM_PRIMARY_STEPS) due = trips + 1;      // past the primary cap every trip takes this tail (m_p is empty by then)
                 next_check = uniform(next_check); due = uniform(due);          // (the compiler would keep them in vector registers)
             }
+            unsigned long long near = __builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p;
             if (m_s) near |= __builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s;
 
             // ---- rare: some lane is at a surface.  It takes its normal in this trip, at the point the distance
@@ -373,6 +417,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             m_s = (go_s & ~left_s) | turn;
         }
         st_evals += trips;
+        st_longest = trips > st_longest ? trips : st_longest;
         if (level) __builtin_amdgcn_s_setprio(0);
         if (expired) break;
 
@@ -437,8 +482,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     }
 
     if (prm.wave_stats && lane == 0) {
-        uint32_t* o = prm.wave_stats + 4 * ((size_t)blockIdx.x * 4 + wave);
-        o[0] = st_evals; o[1] = st_norms; o[2] = (uint32_t)(__builtin_amdgcn_s_memtime() - st_t0); o[3] = st_norm_cycles;
+        uint32_t* o = prm.wave_stats + 8 * ((size_t)blockIdx.x * 4 + wave);
+        const uint64_t st_t1 = __builtin_amdgcn_s_memtime();
+        o[0] = st_evals; o[1] = st_norms; o[2] = (uint32_t)(st_t1 - st_t0); o[3] = st_norm_cycles;
+        o[4] = (uint32_t)st_r0; o[5] = (uint32_t)__builtin_amdgcn_s_memrealtime(); o[6] = tiles_done; o[7] = st_longest;
     }
 }
 

@@ -34,6 +34,12 @@
 #ifndef RM_SINGLE_CHUNK
 #define RM_SINGLE_CHUNK    1
 #endif
+#ifndef RM_MERGE_ALWAYS      // 1: a single frame's cheap tiles share one list and go four per atomic too
+#define RM_MERGE_ALWAYS    0
+#endif
+#ifndef RM_PRIO_HISTORY      // 1: tiles the previous launch filed as long start at a raised priority
+#define RM_PRIO_HISTORY    0
+#endif
 #ifndef RM_PRIO_LEVELS       // how far a long tile's priority rises (1..3), a step at a time (device_render.h)
 #define RM_PRIO_LEVELS     3
 #endif
@@ -93,7 +99,7 @@ struct RenderParams {
     uint8_t* rgba;  size_t pitch;
     uint8_t* hit;   size_t hit_pitch;
     uint8_t* lum;   size_t lum_pitch;   // optional luminance plane, 1 B/px (rm_set_luminance_output)
-    uint32_t* wave_stats;         // optional diagnostics, 4 dwords per wavefront
+    uint32_t* wave_stats;         // optional diagnostics, 8 dwords per wavefront
     uint32_t* status;             // RM_STATUS_DWORDS: tiles finished (running counters) and the watchdog flag
     // tile scheduler (device_render.h): this frame owns set_cur (all zero when it starts), reads the
     // lists the previous frame wrote (counts in set_prev), and zeroes set_next for the frame after it
