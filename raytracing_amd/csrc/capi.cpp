@@ -56,6 +56,7 @@ struct rm_ctx {
     uint32_t* sched = nullptr;        // [3 sets][2 x ([8 heads][8 buckets][list_cap] + [overflow_cap])][status]
     uint32_t seq = 0;                 // launch sequence number
     uint32_t list_cap = 0, overflow_cap = 0;
+    bool adaptive_grid = true;        // the grid follows the previous launch's work and longest tile (render_blocks)
     bool feedback = true;             // launches file their tiles by cost for the next launch
     bool history = false;             // the previous launch did, with the same tile numbering...
     size_t history_frames = 0;        // ...for this many frames: a launch of more frames starts in natural order
@@ -63,6 +64,13 @@ struct rm_ctx {
     // wavefronts report finished, both modulo 2^32
     uint32_t* status_host = nullptr;  // pinned copy of the device's status block
     uint32_t expected_done = 0;
+    // what the last checked launches measured (judge_status), for the next launch's grid (render_blocks)
+    uint32_t trips_seen = 0;          // running sum of march-loop trips at the last check
+    uint32_t launches_unchecked = 0;  // launches since then
+    size_t unchecked_tiles = 0;       // their tiles
+    double trips_per_tile = 0;        // mean of the launches last checked (0: nothing measured yet)
+    uint32_t longest_tile = 0;        // trips of the longest tile of the last launch checked
+    uint32_t last_slot = 0;           // RM_STATUS_LONGEST slot of the last launch
     uint32_t boost_age = 48;
     unsigned long long watchdog = 1ull << 36;
     bool cull = true;                 // bounding-sphere tests in union chains (scene_build.cpp)
@@ -131,6 +139,7 @@ void point_at_schedule(rm::RenderParams& p, uint32_t* sched, uint32_t seq, uint3
     p.list_cap = list_cap;
     p.overflow_cap = overflow_cap;
     p.status = lists + 2 * group;
+    p.stat_slot = seq & 1u;
 }
 
 void fill_params(const rm_ctx* c, rm::RenderParams& p) {
@@ -174,6 +183,16 @@ hipError_t reset_schedule(rm_ctx* c) {
 // persistent grid: what the chip holds at once, or fewer when the image has few tiles
 size_t local_tiles(const rm_ctx* c) { return ((c->width + 7) / 8) * ((c->local_rows + 7) / 8); }
 
+// A launch is as long as its longest tile (one wavefront, a chain of dependent steps) or as its work spread
+// over the chip, whichever is more, and a wavefront is the faster the fewer share its SIMD: with `trips`
+// march-loop trips in all and `longest` in the costliest tile, more than trips / longest wavefronts only slow
+// that tile down (chair 4K, one frame per launch: 8192 wavefronts 0.47 ms, 4096 0.35 ms; a launch of 8 frames,
+// or infinity.sce, has work for every wavefront the chip holds).  Both figures are the previous launch's.
+size_t wanted_waves(const rm_ctx* c, size_t tiles) {
+    if (c->trips_per_tile <= 0 || c->longest_tile == 0) return ~size_t(0);
+    return static_cast<size_t>(c->trips_per_tile * static_cast<double>(tiles) / c->longest_tile) + 1;
+}
+
 unsigned render_blocks(const rm_ctx* c, bool jit, size_t frames) {
     const size_t tiles = local_tiles(c) * frames;
     // Four wavefronts per workgroup, and enough tiles per wavefront that starting it and having it
@@ -187,7 +206,12 @@ unsigned render_blocks(const rm_ctx* c, bool jit, size_t frames) {
     size_t per_cu = static_cast<size_t>(jit ? c->jit.blocks_per_cu : c->blocks_per_cu);
     if (const char* env = std::getenv("RM_BLOCKS_PER_CU"))   // experiments only
         if (std::atoi(env) > 0) per_cu = static_cast<size_t>(std::atoi(env));
-    const size_t resident = static_cast<size_t>(c->cus) * per_cu;
+    size_t resident = static_cast<size_t>(c->cus) * per_cu;
+    if (!std::getenv("RM_BLOCKS_PER_CU") && c->adaptive_grid) {
+        const size_t by_work = (wanted_waves(c, tiles) + 3) / 4;
+        const size_t floor = static_cast<size_t>(c->cus) * 2;            // never below two workgroups per CU
+        if (by_work < resident) resident = by_work > floor ? by_work : floor;
+    }
     return static_cast<unsigned>(want < resident ? want : resident);
 }
 
@@ -202,8 +226,11 @@ int launch_frame(rm_ctx* c, uint32_t* wave_stats, size_t* waves) {
     hipError_t e = jit ? rm::jit_launch_render(c->jit, p, blocks, c->stream)
                        : rm::launch_render(p, blocks, c->lds_bytes, c->stream);
     if (e == hipSuccess) {
-        ++c->seq; c->history = c->feedback; c->history_frames = c->nframes;
+        c->history = c->feedback; c->history_frames = c->nframes;
         c->expected_done += static_cast<uint32_t>(local_tiles(c) * c->nframes);
+        ++c->launches_unchecked; c->unchecked_tiles += local_tiles(c) * c->nframes;
+        c->last_slot = c->seq & 1u;
+        ++c->seq;
     }
     return static_cast<int>(e);
 }
@@ -216,9 +243,21 @@ hipError_t fetch_status(rm_ctx* c) {
     return hipMemcpyAsync(c->status_host, status_block(c), RM_STATUS_DWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
 }
 int judge_status(rm_ctx* c) {
-    uint32_t done = 0;
-    for (int k = 0; k < RM_STATUS_COUNTERS; ++k) done += c->status_host[k * RM_STATUS_STRIDE];
+    uint32_t done = 0, trips = 0, longest = 0;
+    for (int k = 0; k < RM_STATUS_COUNTERS; ++k) {
+        const uint32_t* line = c->status_host + k * RM_STATUS_STRIDE;
+        done += line[0];
+        trips += line[RM_STATUS_TRIPS];
+        if (line[RM_STATUS_LONGEST + c->last_slot] > longest) longest = line[RM_STATUS_LONGEST + c->last_slot];
+    }
+    if (c->launches_unchecked) {
+        c->trips_per_tile = c->unchecked_tiles ? static_cast<double>(trips - c->trips_seen) / static_cast<double>(c->unchecked_tiles) : 0;
+        c->longest_tile = longest;
+        c->launches_unchecked = 0; c->unchecked_tiles = 0;
+    }
+    c->trips_seen = trips;
     if (done == c->expected_done && c->status_host[RM_STATUS_FLAG] == 0) return RM_OK;
+    c->trips_per_tile = 0; c->longest_tile = 0;
     c->expected_done = done;
     c->history = false;
     (void)hipMemsetAsync(c->sched, 0, 3 * RM_SET_DWORDS * sizeof(uint32_t), c->stream);
@@ -337,6 +376,7 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     c->blocks_per_cu = (rm::render_occupancy(lds, &occ) == hipSuccess && occ > 0) ? occ : 1;
     c->scene = std::move(built);
     c->have_scene = true;
+    c->trips_per_tile = 0; c->longest_tile = 0;        // measured on another scene
     return RM_OK;
 }
 
@@ -396,6 +436,7 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     rm_ctx* c = new (std::nothrow) rm_ctx;
     if (!c) return static_cast<int>(hipErrorOutOfMemory);
     c->device = device; c->width = width; c->height = height;
+    if (const char* env = std::getenv("RM_ADAPTIVE_GRID")) c->adaptive_grid = std::atoi(env) != 0;      // experiments only
     if (const char* env = std::getenv("RM_JIT")) c->jit_mode = std::atoi(env) < 0 ? 0 : std::atoi(env) > 3 ? 3 : std::atoi(env);
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
@@ -566,6 +607,7 @@ int rm_set_batch(rm_ctx* c, size_t frames, size_t rgba_frame_stride_bytes, size_
         (void)hipFree(c->sched);
         c->sched = sched; c->overflow_cap = overflow_cap; c->list_cap = list_cap;
         c->history = false; c->seq = 0; c->expected_done = 0;
+        c->trips_seen = 0; c->launches_unchecked = 0; c->unchecked_tiles = 0; c->trips_per_tile = 0; c->longest_tile = 0;
     }
     if (c->out == c->fb) {               // a caller-owned output needs no planes of the context's own
         int rc = grow_framebuffer(c, frames);

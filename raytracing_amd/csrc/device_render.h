@@ -59,6 +59,8 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
 
     // this frame found its scheduler set at zero; leave the next frame's at zero too
     if (blockIdx.x == 0 && threadIdx.x < RM_SET_LINES) prm.set_next[threadIdx.x * RM_QUEUE_STRIDE] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < RM_STATUS_COUNTERS)        // the longest-tile slot of the launch after this one
+        prm.status[threadIdx.x * RM_STATUS_STRIDE + RM_STATUS_LONGEST + (prm.stat_slot ^ 1u)] = 0;
 
     const uint32_t tiles_x = (prm.width + 7) >> 3, tiles_y = (prm.local_rows + 7) >> 3;
     const uint32_t ntiles_frame = tiles_x * tiles_y;
@@ -95,12 +97,12 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // a_ticket: first place of the run of a_run places this wave holds in the head's sequence (one
     // place among the costly tiles, which must spread over the waves; RM_QUEUE_CHUNK among the cheap
     // ones at its end); a_pos: how many of them it has used
-    // Cheap tiles in runs, and in one unordered list, only in a launch of several frames, where the
-    // counters' throughput is what binds (measured on chair 4K: 0.335 -> 0.284 ms per frame at 8 frames
-    // per launch); a single frame is as long as its longest tile plus its share of the chip, and gains nothing
-    // from either (kernel_params.h RM_SINGLE_CHUNK).
-    const bool merged = RM_MERGE_ALWAYS || prm.nframes > 1;
-    const uint32_t pull_chunk = merged ? RM_QUEUE_CHUNK : RM_SINGLE_CHUNK;
+    // Cheap tiles go in runs and share one unordered list because the counters' throughput binds: a word
+    // takes ~88 atomics per microsecond, and a 4K frame at a place per atomic is 16 200 pulls on each of the 8
+    // heads - 0.18 ms of a frame that the arithmetic renders in 0.23 (measured per frame on chair 4K: 0.335 ->
+    // 0.284 ms at 8 frames per launch in round 1; one frame per launch 0.42 -> 0.35 ms and 8K 1.52 -> 1.09 in
+    // round 2).  Without history (natural order) the costly tiles are anywhere, so places go one at a time.
+    const uint32_t pull_chunk = ordered ? RM_QUEUE_CHUNK : 1;
     uint32_t a_cursor = 0, a_head = home, a_total = 0, a_ticket = 0, a_run = 1, a_pos = 0;   // a_cursor: heads tried so far
     uint32_t a_cum[RM_COST_BUCKETS];                                   // running list lengths of a_head
     bool a_done = false;
@@ -441,12 +443,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // ---- file the tile under its cost for the next frame
         KernargParams* fp = kernarg_params();
         if (fp->feedback) {
-            // a single frame keeps its cheap tiles in order too (three more buckets, a place at a time):
-            // its end is as even as the order of its last tiles
             const uint32_t b = trips >= 384 ? 0 : trips >= 192 ? 1 : trips >= 96 ? 2 : trips >= 48 ? 3 : trips >= 24 ? 4
-                             : merged ? RM_CHEAP_BUCKET : trips >= 12 ? 5 : trips >= 6 ? 6 : 7;
+                             : RM_CHEAP_BUCKET;
             uint32_t at;
-            if (b == RM_CHEAP_BUCKET && merged) {   // places in the cheap list are taken RM_QUEUE_CHUNK at a time
+            if (b == RM_CHEAP_BUCKET) {   // places in the cheap list are taken RM_QUEUE_CHUNK at a time
                 if (r_left == 0) { r_base = uniform(bump(RM_SET_COUNT(home, RM_CHEAP_BUCKET), RM_QUEUE_CHUNK)); r_left = RM_QUEUE_CHUNK; }
                 at = r_base + (RM_QUEUE_CHUNK - r_left);
                 --r_left;
@@ -475,9 +475,12 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // what the host checks a launch against: tiles rendered, and whether the watchdog ended anything
     if (lane == 0) {
         uint32_t* status = kernarg_params()->status;
-        if (tiles_done)
-            __hip_atomic_fetch_add(status + (blockIdx.x & (RM_STATUS_COUNTERS - 1)) * RM_STATUS_STRIDE, tiles_done,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t* line = status + (blockIdx.x & (RM_STATUS_COUNTERS - 1)) * RM_STATUS_STRIDE;
+        if (tiles_done) {
+            __hip_atomic_fetch_add(line, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(line + RM_STATUS_TRIPS, st_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(line + RM_STATUS_LONGEST + kernarg_params()->stat_slot, st_longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (expired) __hip_atomic_fetch_or(status + RM_STATUS_FLAG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 

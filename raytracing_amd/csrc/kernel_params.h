@@ -27,16 +27,6 @@
 #ifndef RM_QUEUE_CHUNK
 #define RM_QUEUE_CHUNK     4
 #endif
-// A single frame's lists stay ordered down to the cheapest tiles and it pulls RM_SINGLE_CHUNK places at a
-// time: measured 1, 2, 4, 8 on the stock scenes (tools/single_frame_probe.py) - within noise of each other
-// (chair 4K 0.45-0.48 ms, 8K 1.48 -> 1.41), because such a launch is as long as its longest tile
-// (0.25 ms of dependent steps, about what a 1080p frame takes in all) plus its share of the chip.
-#ifndef RM_SINGLE_CHUNK
-#define RM_SINGLE_CHUNK    1
-#endif
-#ifndef RM_MERGE_ALWAYS      // 1: a single frame's cheap tiles share one list and go four per atomic too
-#define RM_MERGE_ALWAYS    0
-#endif
 #ifndef RM_PRIO_HISTORY      // 1: tiles the previous launch filed as long start at a raised priority
 #define RM_PRIO_HISTORY    0
 #endif
@@ -55,7 +45,12 @@
 // the tiles it finished to one of RM_STATUS_COUNTERS running counters when it leaves (spread over that many
 // words so that the end of a launch is not 8000 atomics on one), and a wavefront that leaves on the
 // watchdog sets the flag word behind them.  The host knows how many tiles it has launched.
+// Beside its tile count every line holds what the host sizes the next launch's grid from: the march-loop
+// trips of the line's wavefronts (running sum) and the trips of their longest tile (a maximum per launch: two
+// slots used in turn, a launch clears the one the next launch will use).
 #define RM_STATUS_COUNTERS 64
+#define RM_STATUS_TRIPS    1       // dword of a line: trips, running sum
+#define RM_STATUS_LONGEST  2       // dwords 2, 3 of a line: longest tile of launch seq (slot seq & 1)
 #define RM_STATUS_STRIDE   16      // dwords between counters
 #define RM_STATUS_FLAG     (RM_STATUS_COUNTERS * RM_STATUS_STRIDE)
 #define RM_STATUS_DWORDS   ((RM_STATUS_COUNTERS + 1) * RM_STATUS_STRIDE)
@@ -101,6 +96,7 @@ struct RenderParams {
     uint8_t* lum;   size_t lum_pitch;   // optional luminance plane, 1 B/px (rm_set_luminance_output)
     uint32_t* wave_stats;         // optional diagnostics, 8 dwords per wavefront
     uint32_t* status;             // RM_STATUS_DWORDS: tiles finished (running counters) and the watchdog flag
+    uint32_t stat_slot;           // which RM_STATUS_LONGEST slot this launch fills (the launch number's parity)
     // tile scheduler (device_render.h): this frame owns set_cur (all zero when it starts), reads the
     // lists the previous frame wrote (counts in set_prev), and zeroes set_next for the frame after it
     uint32_t* set_cur;
