@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the extra frame-per-launch measurement (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=0, help="contexts taking launches in turn (0 = 1 for N=1, 3 for N>1)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="frames whose tiles one launch pools (rm_set_batch), 1..32; 0 = 8")
+                    help="most frames whose tiles one launch pools (rm_set_batch), 1..32; 0 = 16")
     ap.add_argument("--warmup-seconds", type=float, default=0.25,
                     help="warm up for at least this long as well as for --warmup frames (clocks, tile order)")
     args = ap.parse_args()
@@ -209,14 +209,14 @@ def main():
         streams.append(st)
 
     band = 0
-    # Frames per launch (rm_set_batch): 8 at every N.  The reference renders a frame per Process()
-    # call; here the tiles of 8 consecutive frames of the sequence form one pool for the persistent
-    # wavefronts, so the few long tiles of a frame (one ray marching ~900 steps is 0.2 ms however idle
-    # the chip is) run beside the short tiles of the others.  At N>1 it is what makes a rank's launch
-    # worth launching: an 8-rank share of ONE frame is too little work to fill the chip for as long as
-    # its longest ray marches (tools/slice_rate.py: 5.2 k shares/s per GPU one at a time, 18-22 k/s
-    # with 8 per launch).  `single_frame_launch` in the output is the frame-at-a-time figure.
-    batch = args.frames_per_launch or 8
+    # Frames per launch (rm_set_batch): up to 16 at every N, and a timed run of K frames goes out in the fewest
+    # launches of nearly equal size (FrameBatcher.plan).  The reference renders a frame per Process() call;
+    # here the tiles of consecutive frames of the sequence form one pool for the persistent wavefronts, so the few
+    # long tiles of a frame (one ray marching ~500 steps is 0.2 ms however idle the chip is) run beside the short
+    # tiles of the others.  At N>1 it is what makes a rank's launch worth launching: an 8-rank share of ONE frame
+    # is too little work to fill the chip for as long as its longest ray marches.  `single_frame_launch` in the
+    # output is the frame-at-a-time figure (the reference's own call pattern).
+    batch = args.frames_per_launch or 16
     batch = max(1, min(32, batch))
     if world > 1:
         # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
@@ -260,13 +260,13 @@ def main():
         with torch.cuda.stream(comm_stream):           # same order of gathers on every rank
             if rehearsal:
                 comm_stream.synchronize()
-                host = bufs[j].cpu()
+                host = bufs[j][:n].cpu()
                 got = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, got, dst=0)
                 if rank == 0:
-                    parts[j].copy_(torch.stack(got))
+                    parts[j][:, :n].copy_(torch.stack(got))
             else:
-                dist.gather(bufs[j], list(parts[j].unbind(0)) if rank == 0 else None, dst=0)
+                dist.gather(bufs[j][:n], list(parts[j][:, :n].unbind(0)) if rank == 0 else None, dst=0)     # the n frames of this launch only
             if rank == 0:
                 for slot in range(n):
                     rm.assemble_luminance(parts[j].data_ptr() + slot * rows_max * w, batch * rows_max * w, w,
@@ -314,6 +314,7 @@ def main():
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     run.launches = 0
+    run.plan(args.steps)                               # launches of nearly equal size
     t0 = time.perf_counter()
     ev0.record(streams[run.ctx])
     for k in range(args.steps):
@@ -352,7 +353,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, **({"rehearsal": True} if rehearsal else {}),
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
-                       "scene_nodes": int(len(nodes)), "contexts_in_flight": in_flight, "frames_per_launch": batch,
+                       "scene_nodes": int(len(nodes)), "contexts_in_flight": in_flight, "frames_per_launch": args.steps / launches, "frames_per_launch_max": batch,
                        "partition": "whole frame" if world == 1 else
                        "row bands of %d dealt round-robin over %d ranks; the %d frames of a launch gathered together to rank 0 "
                        "as luminance planes (1 B/px, RCCL), RGBA8 frames rebuilt there" % (band, world, batch)},
@@ -362,22 +363,38 @@ def main():
             "kernel_ms": kernel_ms, "launches": launches,
         }
         if want:
-            flops = want["counters"]["flops"] / world * args.steps / launches      # per launch: 1/N of each of its frames
-            achieved = flops / (kernel_ms * 1e-3) / 1e12
+            # FLOPs of one launch (1/N of each of its frames), counted by the CPU restatement.
+            # The kernel marches a primary ray only where it can be near the scene's volume (ray windows,
+            # include/raymarching_amd.h): the FLOPs it EXECUTES are those of the windowed march, restated and
+            # counted in the oracle too (tests/golden/frames.json "windowed"), and they, not the reference march's,
+            # are what `achieved` and `frac` are made of.  `reference_march` prices the same frames at the
+            # reference's work (every ray marched to RM_MAX_DIST): the rate a kernel without windows would have to
+            # sustain for this frame time - a speed-up figure, not a utilisation (it can exceed the peak).
+            windows = os.environ.get("RM_RAY_WINDOWS", "1") != "0" and "windowed" in want
+            done = want["windowed"] if windows else want
+            per_launch = 1.0 / world * args.steps / launches
+            achieved = done["counters"]["flops"] * per_launch / (kernel_ms * 1e-3) / 1e12
+            reference = want["counters"]["flops"] * per_launch / (kernel_ms * 1e-3) / 1e12
             traffic = measured_traffic(args.workload, args.steps / launches) if world == 1 else None
             out["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                                "traffic": traffic["bytes"] if traffic else None,
                                "traffic_source": traffic["source"] if traffic else None,
-                               "algorithmic_flops_per_ray": want["flops_per_ray"],
+                               "algorithmic_flops_per_ray": done["flops_per_ray"], "ray_windows": windows,
                                "peak_no_fma": FP32_VALU_NO_FMA_TFLOPS, "frac_of_no_fma_peak": achieved / FP32_VALU_NO_FMA_TFLOPS,
+                               "reference_march": {"flops_per_ray": want["flops_per_ray"], "achieved": reference,
+                                                   "frac": reference / FP32_VALU_PEAK_TFLOPS},
                                "note": "the path is bound by fp32 vector issue, not by HBM or MFMA (SURVEY.md 8d). "
-                                       "achieved = algorithmic FLOPs of one launch, counted by the CPU restatement "
-                                       "(SURVEY.md appendix D: add/sub/mul/div/sqrt/floor/min/max = 1), over the "
-                                       "kernel's average duration; peak = 157.3 TFLOP/s of FMAs.  Results must match "
+                                       "achieved = FLOPs the kernel executes in one launch (the windowed march's, counted by "
+                                       "the CPU restatement; SURVEY.md appendix D: add/sub/mul/div/sqrt/floor/min/max = 1) "
+                                       "over the kernel's average duration; peak = 157.3 TFLOP/s of FMAs.  reference_march: "
+                                       "the same frames priced at the FLOPs of the reference's march, which takes every ray "
+                                       "to RM_MAX_DIST - not a utilisation.  Results must match "
                                        "the reference bit for bit, so nothing is contracted into an FMA and sqrt and "
                                        "division are correctly rounded: peak_no_fma is what the chip issues then "
-                                       "(measured: tools/microbench/valu_peak.hip)",
+                                       "(measured: tools/microbench/valu_peak.hip)"
+                                       + ("; csg1024: the kernel also skips union members behind bounding-sphere tests, which "
+                                          "the count does not see - an upper bound of the work done" if scene == "csg1024" else ""),
                                "hbm": {"achieved": w * h * 4 / world * args.steps / launches / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "bytes_per_ray": 4}}
         if world == 1 and batch > 1 and not args.no_single_frame:

@@ -126,6 +126,25 @@ enum rm_bazo_layout {
 #define RM_MATERIAL_G     .7f
 #define RM_MATERIAL_B     1.f
 
+/* Ray windows (raymarching_amd.h; no counterpart in the reference): a volume with
+ *     DIST(root, x) >= distance(x, centre or axis) - r     at every point x. */
+enum rm_bound_kind { RM_BOUND_NONE = 0, RM_BOUND_SPHERE = 1, RM_BOUND_CYLINDER = 2 };
+typedef struct rm_scene_bound {
+    uint32_t kind;             /* enum rm_bound_kind                               */
+    float c[3];                /* centre of the sphere / a point of the axis       */
+    float u[3];                /* unit direction of the cylinder's axis            */
+    float r;                   /* radius                                           */
+} rm_scene_bound;
+/* A primary ray is marched while it can be within RM_WINDOW_MARGIN of the volume.  The
+ * margin covers what separates the march from the ideal ray: positions and the
+ * travelled distance are running float sums (up to RM_PRIMARY_STEPS steps of coordinates
+ * up to RM_WINDOW_MAX_COORD + RM_MAX_DIST: 3.1 units at worst), DIST itself is rounded
+ * (well under a unit at such coordinates), and a surface is RM_MIN_DIST thick. */
+#define RM_WINDOW_MARGIN     8.f
+#define RM_WINDOW_SLACK      1.f        /* added to the distance at which the ray leaves the volume */
+#define RM_WINDOW_MAX_COORD  16384.f    /* rays starting farther out, and volumes centred or reaching farther out, get no window */
+#define RM_WINDOW_MIN_SIN2   .01f       /* rays within 5.7 degrees of a cylinder's axis get no window */
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,12 @@ def lib():
         L.rmo_render.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rmo_render.restype = C.c_double
+        L.rmo_render_rows_windowed.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                               C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rmo_render_rows_windowed.restype = None
+        L.rmo_render_windowed.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rmo_render_windowed.restype = C.c_double
         L.rmo_default_info.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.rmo_default_info.restype = None
         L.rmo_camera_script.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -196,10 +202,22 @@ def counters_dict(c):
     return d
 
 
+BOUND_DTYPE = np.dtype([("kind", "<u4"), ("c", "<f4", (3,)), ("u", "<f4", (3,)), ("r", "<f4")])   # rm_scene_bound
+assert BOUND_DTYPE.itemsize == 32
+
+
+def bound_record(kind, c=(0, 0, 0), u=(0, 0, 0), r=0.0):
+    b = np.zeros(1, dtype=BOUND_DTYPE)
+    b["kind"], b["c"], b["u"], b["r"] = kind, c, u, r
+    return b
+
+
 def render(nodes, width, height, info, threads=1, want_hit=True, want_evals=False,
-           want_counters=False, rows=None):
+           want_counters=False, rows=None, window=None):
     """Render a frame (or rows=(y0,y1) of it, single-threaded) on the CPU.
 
+    window: an rm_scene_bound record (BOUND_DTYPE) - the product's windowed march restated
+    (rmo_render_windowed); None: the reference's march.
     Returns dict(rgba[H,W,4] u8, hit[H,W] u8, evals[H,W] u16, counters, seconds)."""
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     info = np.ascontiguousarray(info, dtype=INFO_DTYPE)
@@ -209,14 +227,16 @@ def render(nodes, width, height, info, threads=1, want_hit=True, want_evals=Fals
     hit = np.zeros((height, width), dtype=np.uint8) if want_hit else None
     evals = np.zeros((height, width), dtype=np.uint16) if want_evals else None
     cnt = np.zeros(len(COUNTER_FIELDS), dtype=np.uint64) if want_counters else None
+    if window is not None:
+        window = np.ascontiguousarray(window, dtype=BOUND_DTYPE)
     if rows is None:
-        secs = lib().rmo_render(_ptr(nodes), nodes.size, width, height, _ptr(info), threads,
-                                _ptr(rgba), _ptr(hit), _ptr(evals), _ptr(cnt))
+        secs = lib().rmo_render_windowed(_ptr(nodes), nodes.size, width, height, _ptr(info), _ptr(window), threads,
+                                         _ptr(rgba), _ptr(hit), _ptr(evals), _ptr(cnt))
     else:
         import time
         t0 = time.perf_counter()
-        lib().rmo_render_rows(_ptr(nodes), nodes.size, width, height, _ptr(info), rows[0], rows[1],
-                              _ptr(rgba), _ptr(hit), _ptr(evals), _ptr(cnt))
+        lib().rmo_render_rows_windowed(_ptr(nodes), nodes.size, width, height, _ptr(info), _ptr(window), rows[0], rows[1],
+                                       _ptr(rgba), _ptr(hit), _ptr(evals), _ptr(cnt))
         secs = time.perf_counter() - t0
     return {"rgba": rgba, "hit": hit, "evals": evals,
             "counters": counters_dict(cnt) if cnt is not None else None, "seconds": secs}

@@ -30,7 +30,7 @@ EXPORTS = [
     "rm_flatten_scene", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
     "rm_set_luminance_output", "rm_assemble_luminance", "rm_set_batch", "rm_set_info_batch",
-    "rm_process_static", "rm_debug_set_watchdog",
+    "rm_process_static", "rm_debug_set_watchdog", "rm_scene_bound_of", "rm_set_ray_windows",
 ]
 
 
@@ -41,6 +41,17 @@ class SceneStats(C.Structure):
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class SceneBound(C.Structure):
+    """rm_scene_bound (include/rm_types.h)."""
+    _fields_ = [("kind", C.c_uint32), ("c", C.c_float * 3), ("u", C.c_float * 3), ("r", C.c_float)]
+
+    def as_dict(self):
+        return {"kind": int(self.kind), "c": [float(v) for v in self.c], "u": [float(v) for v in self.u], "r": float(self.r)}
+
+
+BOUND_NONE, BOUND_SPHERE, BOUND_CYLINDER = 0, 1, 2
 
 
 class RaymarchError(RuntimeError):
@@ -103,6 +114,8 @@ def lib():
             "rm_selftest_math": [vp, vp, sz, C.POINTER(C.c_ulonglong), vp],
             "rm_set_short_math": [vp, i32],
             "rm_set_culling": [vp, i32],
+            "rm_set_ray_windows": [vp, i32],
+            "rm_scene_bound_of": [vp, sz, C.POINTER(SceneBound)],
             "rm_eval_points": [vp, i32, sz, vp, sz, vp, vp],
             "rm_eval_rays": [vp, vp, sz, vp],
             "rm_debug_wave_stats": [vp, vp, sz, C.POINTER(sz)],
@@ -162,6 +175,14 @@ def flatten_scene(nodes, listing_cap=1 << 20):
     buf = C.create_string_buffer(listing_cap)
     _check(lib().rm_flatten_scene(_ptr(nodes), nodes.size, C.byref(st), buf, listing_cap), "rm_flatten_scene")
     return st.as_dict(), buf.value.decode()
+
+
+def scene_bound(nodes):
+    """Host-only: the volume outside of which the scene's distance function is provably large (rm_scene_bound_of)."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    b = SceneBound()
+    _check(lib().rm_scene_bound_of(_ptr(nodes), nodes.size, C.byref(b)), "rm_scene_bound_of")
+    return b
 
 
 def jit_check(nodes, arch="gfx950", want_source=False, cap=1 << 20, assume_exact_divisors=False):
@@ -268,6 +289,9 @@ class Raymarching:
 
     def set_culling(self, enable=True):
         _check(lib().rm_set_culling(self._ctx, 1 if enable else 0), "rm_set_culling")
+
+    def set_ray_windows(self, enable=True):
+        _check(lib().rm_set_ray_windows(self._ctx, 1 if enable else 0), "rm_set_ray_windows")
 
     def set_short_math(self, enable=True):
         _check(lib().rm_set_short_math(self._ctx, 1 if enable else 0), "rm_set_short_math")

@@ -19,10 +19,18 @@ class FrameBatcher:
         self.pending = []
         self.launches = 0
         self.last = None              # (context index, slot of the last frame in its launch)
+        self.sizes = []               # launch sizes still to come of a planned run (plan)
+
+    def plan(self, total):
+        """A run of `total` frames known in advance goes out in the fewest launches the batch allows, all of
+        nearly the same size (20 frames at up to 8 per launch: 7, 7, 6, not 8, 8, 4): a short last launch has
+        the same long tiles to wait for as a full one and fewer cheap tiles to run beside them."""
+        n = -(-int(total) // self.batch)
+        self.sizes = [int(total) // n + (1 if k < int(total) % n else 0) for k in range(n)] if n else []
 
     def step(self, info):
         self.pending.append(info)
-        if len(self.pending) == self.batch:
+        if len(self.pending) == (self.sizes[0] if self.sizes else self.batch):
             self.flush()
 
     def flush(self):
@@ -36,6 +44,8 @@ class FrameBatcher:
         rm.set_info_batch(np.concatenate(self.pending))      # n <= batch cameras: this launch renders n frames
         rm.process_async()
         self.launches += 1
+        if self.sizes:
+            self.sizes.pop(0)
         self.last = (j, n - 1)
         self.ctx, self.pending = (j + 1) % len(self.ctxs), []
         if self.after:

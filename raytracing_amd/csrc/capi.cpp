@@ -74,6 +74,8 @@ struct rm_ctx {
     uint32_t boost_age = 48;
     unsigned long long watchdog = 1ull << 36;
     bool cull = true;                 // bounding-sphere tests in union chains (scene_build.cpp)
+    rm_scene_bound bound = {};        // the current scene's volume (scene_bound.cpp); kind RM_BOUND_NONE: none
+    bool ray_windows = true;          // primary rays are marched only where they can be near it (rm_set_ray_windows)
     bool short_math = true;           // scenes may use div_const for divisors the device has proved
     uint32_t exact_divisors = 0;      // how many of the current scene's divisor constants were
     int cus = 1, blocks_per_cu = 1;   // of the device / of the ahead-of-time kernel at lds_bytes
@@ -164,6 +166,11 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     for (size_t f = 0; f < RM_MAX_BATCH; ++f) p.cams[f] = c->cams[f];
     p.boost_age = c->boost_age;
     p.watchdog = c->watchdog;
+    if (c->ray_windows && c->bound.kind != RM_BOUND_NONE) {
+        p.bound_kind = c->bound.kind;
+        for (int k = 0; k < 3; ++k) { p.bound_c[k] = c->bound.c[k]; p.bound_u[k] = c->bound.u[k]; }
+        p.bound_R = c->bound.r + RM_WINDOW_MARGIN;
+    }
     point_at_schedule(p, c->sched, c->seq, c->list_cap, c->overflow_cap);
     p.feedback = c->feedback ? 1u : 0u;
     // the lists of the previous launch hold the tiles of its frames: a launch of fewer frames skips the
@@ -375,6 +382,7 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
     int occ = 0;
     c->blocks_per_cu = (rm::render_occupancy(lds, &occ) == hipSuccess && occ > 0) ? occ : 1;
     c->scene = std::move(built);
+    rm::scene_bound(nodes, n, &c->bound);
     c->have_scene = true;
     c->trips_per_tile = 0; c->longest_tile = 0;        // measured on another scene
     return RM_OK;
@@ -437,6 +445,7 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     if (!c) return static_cast<int>(hipErrorOutOfMemory);
     c->device = device; c->width = width; c->height = height;
     if (const char* env = std::getenv("RM_ADAPTIVE_GRID")) c->adaptive_grid = std::atoi(env) != 0;      // experiments only
+    if (const char* env = std::getenv("RM_RAY_WINDOWS")) c->ray_windows = std::atoi(env) != 0;          // experiments only
     if (const char* env = std::getenv("RM_JIT")) c->jit_mode = std::atoi(env) < 0 ? 0 : std::atoi(env) > 3 ? 3 : std::atoi(env);
     hipError_t e = hipStreamCreate(&c->own_stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
@@ -895,6 +904,22 @@ int rm_selftest_math(rm_ctx* c, const float* divisors, size_t n, unsigned long l
     std::vector<unsigned long long> bad;
     HIP_TRY(check_divisors(c, cs, 0u, 1ull << 32, bad));
     for (size_t i = 0; i < n; ++i) div_mismatches[i] = bad[i];
+    return RM_OK;
+}
+
+int rm_scene_bound_of(const rm_node* nodes, size_t n, rm_scene_bound* out) {
+    if (!nodes || !n || !out) return RM_ERR_INVALID_ARG;
+    rm::SceneBuild built;                        // validation: child links inside the table and forward
+    const int rc = rm::build_scene(nodes, n, built, nullptr, false);
+    if (rc != RM_OK) return rc;
+    rm::scene_bound(nodes, n, out);
+    return RM_OK;
+}
+
+int rm_set_ray_windows(rm_ctx* c, int enable) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    c->ray_windows = enable != 0;
+    c->trips_per_tile = 0; c->longest_tile = 0;       // measured under the other setting
     return RM_OK;
 }
 

@@ -49,6 +49,53 @@ __device__ __forceinline__ KernargParams* kernarg_params() {
     return p;
 }
 
+// Ray windows (include/raymarching_amd.h; no counterpart in the reference, which marches every ray until it
+// has travelled RM_MAX_DIST, :707-714).  The host derives from the node tree a sphere, or a cylinder around a
+// lattice's axis, of radius r with DIST(root, x) >= dist(x, centre or axis) - r everywhere (scene_bound.cpp).
+// A primary ray can find a surface only while it is inside that volume grown by RM_WINDOW_MARGIN: outside of it
+// DIST is more than the margin less what separates the march from the ideal ray (rm_types.h), hundreds of times
+// RM_MIN_DIST.  So a ray that never enters the grown volume is the black pixel of a miss (:622) without a step,
+// and one that does is marched no farther than where it leaves it for good: `t_end` takes RM_MAX_DIST's place in
+// the test of :712.  The steps that ARE made are the reference's, from the ray's first on (the march is chaotic:
+// where a ray lands depends on every step before), so pixels and hit masks do not change by a bit.
+// The intersection is worked out in fp32 with its own rounding priced in: `mag` bounds every magnitude that
+// enters, and the nearest approach |w| of the ray to the centre / axis is off by less than e_w, its place s0 along
+// the ray by less than e_s0 (5e-6 mag is 80 half-ulps of mag: the sums below are a dozen operations long, and
+// for a cylinder the division by a = sin^2 of the angle between ray and axis stretches them by 1/a and 1/sqrt(a)).
+// The volume is grown by e_w on top of the margin, and s0's error goes into the slack.
+// Returns false for a ray that can be dropped.  t_end <= RM_MAX_DIST.
+__device__ __forceinline__ bool ray_window(KernargParams* kp, P3 o, P3 d, float& t_end) {
+    t_end = RM_MAX_DIST;
+    const uint32_t kind = kp->bound_kind;
+    if (kind == RM_BOUND_NONE) return true;                        // wave-uniform
+    const float R = kp->bound_R;
+    const float ocx = o.x - kp->bound_c[0], ocy = o.y - kp->bound_c[1], ocz = o.z - kp->bound_c[2];
+    // ray origins far out get no window (false for NaN as well)
+    bool usable = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= RM_WINDOW_MAX_COORD;
+    float px = ocx, py = ocy, pz = ocz, qx = d.x, qy = d.y, qz = d.z;       // origin and direction, across the axis for a cylinder
+    float rs = 1.f;                                                // 1 / sin of the angle between ray and axis
+    if (kind == RM_BOUND_CYLINDER) {
+        const float ux = kp->bound_u[0], uy = kp->bound_u[1], uz = kp->bound_u[2];
+        const float ou = ocx * ux + ocy * uy + ocz * uz, du = d.x * ux + d.y * uy + d.z * uz;
+        px -= ou * ux; py -= ou * uy; pz -= ou * uz;
+        qx -= du * ux; qy -= du * uy; qz -= du * uz;
+        const float a = qx * qx + qy * qy + qz * qz;
+        usable = usable && a >= RM_WINDOW_MIN_SIN2;
+        rs = __builtin_amdgcn_rsqf(a);                             // v_rsq_f32 is good to an ulp: inside s0's allowance below
+    }
+    const float inv_a = rs * rs;
+    const float s0 = -(px * qx + py * qy + pz * qz) * inv_a;       // where the ray is nearest to the centre / axis
+    const float wx = px + s0 * qx, wy = py + s0 * qy, wz = pz + s0 * qz;
+    const float p2 = wx * wx + wy * wy + wz * wz;                  // and how near, squared
+    const float mag = fabsf(ocx) + fabsf(ocy) + fabsf(ocz) + R;
+    const float Re = R + 5e-6f * mag * rs;
+    const float gap = Re * Re - p2;                                // >= 0: the ray passes through the grown volume
+    // (the hardware's one-instruction square root, an ulp off at most, inside a factor that rounds it up)
+    const float leave = s0 + __builtin_amdgcn_sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f + (RM_WINDOW_SLACK + 5e-6f * mag * inv_a + 2e-6f * fabsf(s0));
+    if (usable && leave < RM_MAX_DIST) t_end = leave;              // (false for NaN)
+    return !(usable && (gap < 0.f || leave < 0.f));
+}
+
 template <class Scene>
 __device__ __forceinline__ void render_body(const RenderParams& prm) {
     Scene scene;
@@ -213,13 +260,19 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
 
         P3 pos, rd;
         make_ray(cam, width, height, (int)px, (int)gy, pos, rd);
-        float t = 0.f, cd = 0.f, n_l = 0.f, shadow = 1.f;
+        // The travelled distance at which a primary lane's march ends (ray_window: RM_MAX_DIST of :712 or less)
+        // lives in the register that holds the lane's shadow term once it has turned to the light: a lane needs
+        // one or the other, and the march loop has no vector register to spare (64 for 8 wavefronts per SIMD).
+        float shadow;
+        const bool may_hit = ray_window(tp, pos, rd, shadow);
+        float& t_lim = shadow;                   // primary lanes only
+        float t = 0.f, cd = 0.f, n_l = 0.f;
         // Which lanes march, and in which phase, is two wave-level masks in scalar registers, not a mode
         // per lane: the tests on them, their updates and the branches they feed are scalar instructions,
         // which issue beside the vector ones, and a compare or select costs 1.7 vector additions here
         // (tools/microbench/valu_peak.hip).  m_p: lanes on their primary march (:626); m_s: lanes on
         // their shadow march (:660).  A lane in neither is done.
-        unsigned long long m_p = __builtin_amdgcn_ballot_w64(in_image), m_s = 0;
+        unsigned long long m_p = __builtin_amdgcn_ballot_w64(in_image && may_hit), m_s = 0;
         // The step caps (:626 I < 500, :660 J < 300) need no counter per lane either: a lane moves every
         // trip it is in a phase, every lane starts its primary march at trip 1 (so its step count is the
         // wave's trip count), and a lane that turns to the light at trip s has made J steps at trip s + J.
@@ -273,7 +326,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                         pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
                         t += cd;
                     }
-                    m_p &= ~__builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST);     // a resting lane's stale t clears a bit that is clear
+                    m_p &= ~__builtin_amdgcn_ballot_w64(t >= t_lim);           // a resting lane's stale t clears a bit that is clear
                     if (m_p == 0) break;
                 } else if (m_p == 0) {
                     // ---- shadow lanes only (:679-690); at a surface: 8 * cd < RM_MIN_DIST (:662)
@@ -374,7 +427,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
                     t += cd;
                 }
-                left_p = trips >= RM_PRIMARY_STEPS ? go_p : (__builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST) & go_p);
+                left_p = trips >= RM_PRIMARY_STEPS ? go_p : (__builtin_amdgcn_ballot_w64(t >= t_lim) & go_p);
             }
 
             // ---- shadow lanes march on (:679-690), those not found behind an occluder

@@ -56,6 +56,10 @@ float divisor_reciprocal(const DivisorSet* exact, float c);
 // cull: put bounding-sphere tests (OP_CULL) in front of the sub-trees of union chains
 int  build_scene(const rm_node* nodes, size_t n, SceneBuild& out, const DivisorSet* exact = nullptr, bool cull = true);
 
+// A volume outside of which DIST(root, x) >= dist(x, volume) - r (scene_bound.cpp); kind RM_BOUND_NONE if the
+// tree offers none.
+void scene_bound(const rm_node* nodes, size_t n, rm_scene_bound* out);
+
 // Human-readable listing of a distance program (tests).
 std::string disassemble(const std::vector<Slot>& program);
 

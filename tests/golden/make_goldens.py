@@ -29,7 +29,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 import kat_scenes  # noqa: E402
 from oracle import oracle as O  # noqa: E402
-from raytracing_amd import scenes  # noqa: E402
+from raytracing_amd import api, scenes  # noqa: E402
 
 HERE = os.path.join(ROOT, "tests", "golden")
 
@@ -52,12 +52,42 @@ def frame_record(nodes, w, h, info, threads):
     return rec, packed
 
 
+def windowed_record(nodes, w, h, info, threads, want):
+    """The same frame by the windowed march (the product's ray windows restated in the oracle): its counters are
+    the FLOPs the product's kernel executes (bench.py's roofline), its pixels must be the plain march's."""
+    b = api.scene_bound(nodes)
+    window = O.bound_record(b.kind, list(b.c), list(b.u), b.r)
+    r = O.render(nodes, w, h, info, threads=threads, want_counters=True, want_evals=True, window=window)
+    assert hashlib.sha256(r["rgba"].tobytes()).hexdigest() == want["rgba_sha256"], "the windowed march changed a pixel"
+    assert int(r["hit"].sum()) == want["hits"]
+    return {"bound": b.as_dict(), "counters": r["counters"], "flops_per_ray": r["counters"]["flops"] / float(w * h),
+            "mean_root_evals": float(r["evals"].mean()), "rays_not_marched": int((r["evals"] == 0).sum()),
+            "oracle_seconds": r["seconds"], "oracle_threads": threads}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also the 4K csg1024 frame (minutes of CPU)")
+    ap.add_argument("--windowed-only", action="store_true",
+                    help="only add the windowed march's counters to the frames already in frames.json (every one of them)")
     args = ap.parse_args()
     threads = os.cpu_count() or 4
     O.build()
+
+    if args.windowed_only:
+        path = os.path.join(HERE, "frames.json")
+        with open(path) as f:
+            frames = json.load(f)
+        info = O.default_info(1, 0)
+        for key, rec in sorted(frames.items(), key=lambda kv: kv[1]["counters"]["flops"]):
+            name = key.rsplit("_", 1)[0]
+            nodes = scenes.csg1024() if name == "csg1024" else O.load_sce(os.path.join(HERE, "scenes", name + ".sce"))
+            rec["windowed"] = windowed_record(nodes, rec["width"], rec["height"], info, threads, rec)
+            print(key, "%.0f -> %.0f flop/ray" % (rec["flops_per_ray"], rec["windowed"]["flops_per_ray"]),
+                  "%.1fs" % rec["windowed"]["oracle_seconds"], flush=True)
+            with open(path, "w") as f:
+                json.dump(frames, f, indent=1, sort_keys=True)
+        return
 
     # ---- node-level known answers
     pts = kat_scenes.points()
@@ -102,6 +132,7 @@ def main():
     for name, w, h in jobs:
         nodes = csg if name == "csg1024" else stock[name]
         rec, packed = frame_record(nodes, w, h, info, threads)
+        rec["windowed"] = windowed_record(nodes, w, h, info, threads, rec)
         key = "%s_%dx%d" % (name, w, h)
         frames[key] = rec
         with open(os.path.join(HERE, "hit_%s.z" % key), "wb") as f:

@@ -268,6 +268,47 @@ def test_kat_scene_frames(name, path):
     assert_same_frame(rgba, hit, ref, "kat_%s_%s" % (name, path))
 
 
+@pytest.mark.parametrize("path", ["jit", "program"])
+def test_ray_windows_change_no_pixel(stock_scenes, path):
+    """Ray windows (include/raymarching_amd.h): with them and without, frames are the oracle's (which marches
+    every ray to RM_MAX_DIST as the reference does), from cameras outside, inside and far from the scene's
+    volume; with them the march loop makes fewer trips."""
+    nodes = stock_scenes["chair"]
+    jit, evaluator = PATHS[path]
+
+    def cam(light, drag, pos=None, wide=None):
+        info = O.default_info(light, drag)
+        if pos is not None:
+            info["StartPos"] = pos
+        if wide is not None:
+            for v in ("StartWVec", "StartHVec"):
+                for a in "xyz":
+                    info[v][a] *= np.float32(wide)
+        return info
+
+    cams = {"default": cam(1, 0), "wide": cam(1, 0, wide=5.0), "sideways": cam(3, 120), "inside": cam(2, 30, pos=(200.0, 10.0, 5.0)),
+            "along_the_axis": cam(2, 180, pos=(200.0, -300.0, -60.0)), "far_below": cam(1, 0, pos=(0.0, 0.0, -2500.0)),
+            "beyond_the_limit": cam(1, 0, pos=(-20000.0, 0.0, 0.0), wide=0.05)}
+    w, h = 320, 240
+    trips = {}
+    with api.Raymarching(w, h) as rm:
+        rm.set_jit(jit)
+        rm.set_nodes(nodes)
+        rm.set_evaluator(evaluator)
+        rm.enable_hit_mask(True)
+        for label, info in cams.items():
+            ref = O.render(nodes, w, h, info, threads=8)
+            for windows in (True, False):
+                rm.set_ray_windows(windows)
+                rm.set_info(info)
+                rm.process()
+                assert_same_frame(rm.read_pixels(), rm.read_hit_mask(), ref, "windows_%s_%s_%d" % (path, label, windows))
+                trips[(label, windows)] = int(rm.wave_stats()[:, 0].sum())
+    assert trips[("wide", True)] < 0.8 * trips[("wide", False)], trips
+    assert trips[("far_below", True)] == 0 < trips[("far_below", False)], trips
+    assert trips[("beyond_the_limit", True)] == trips[("beyond_the_limit", False)], trips
+
+
 def test_ragged_sizes(stock_scenes):
     """Image sizes that are not multiples of the 16x16 workgroup block."""
     info = O.default_info(1, 0)

@@ -306,6 +306,16 @@ def test_a_launch_that_is_not_full_sets_no_batch(steps, batch, contexts, want):
     assert [name for name, call, _ in log if call == "process_async"] == [k % contexts for k in range(len(want))]
     assert run.last == ((len(want) - 1) % contexts, want[-1] - 1)
     assert seen == [x for k, n in enumerate(want) for x in (("before", k % contexts), ("after", k % contexts, n))]
+    # the same run planned: as few launches, of nearly equal size, and still nothing but cameras and launches
+    del log[:]
+    run = FrameBatcher(ctxs, batch)
+    run.plan(steps)
+    for k in range(steps):
+        run.step(info)
+    run.flush()
+    sizes = [n for _, call, n in log if call == "set_info_batch"]
+    assert len(sizes) == len(want) and sum(sizes) == steps and max(sizes) - min(sizes) <= 1 and max(sizes) <= batch
+    assert not [c for c in log if c[1] == "set_batch"]
 
 
 def test_bench_sets_the_batch_once_before_timing():

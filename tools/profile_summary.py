@@ -26,15 +26,15 @@ note = argv[2] if len(argv) > 2 else ""
 scene, W, H = WORKLOADS[workload]
 G = os.path.join(ROOT, "gpurun_out")
 KERNEL = "rm_render_jit"
-PMC_WARM_LAUNCHES, PMC_LAUNCHES = 1, 3      # the counter passes run --steps 24 --warmup 8 at 8 frames per launch
+PMC_LAUNCHES = 2      # the counter passes run --steps 32 --warmup 16 at 16 frames per launch: the last two launches are the timed ones
 
-lines = ["# %s: %s (%s.sce %dx%d), MI355X, one context, launches of 8 frames back to back; all figures per launch%s" % (tag, workload, scene, W, H, (" -- " + note) if note else ""),
+lines = ["# %s: %s (%s.sce %dx%d), MI355X, one context, launches of 16 frames back to back; all figures per launch%s" % (tag, workload, scene, W, H, (" -- " + note) if note else ""),
          "# command per pass: rocprofv3 [--kernel-trace --stats | --pmc <counters> --kernel-trace] -- python3 bench.py --workload %s --steps K --warmup W --no-cpu-baseline --no-single-frame" % workload,
          "# (tools/profile_round.sh, summarised by tools/profile_summary.py; every counter pass is a run of its own)", ""]
 
 # ---- kernel trace
 db_path = glob.glob(os.path.join(G, tag + "_trace", "**", "*.db"), recursive=True)
-lines.append("## kernel trace (--steps 96 --warmup 16, 8 frames per launch)")
+lines.append("## kernel trace (--steps 96 --warmup 16, 16 frames per launch)")
 avg_us = None
 if db_path:
     db = sqlite3.connect(db_path[0])
@@ -73,7 +73,7 @@ lines.append("")
 
 # ---- derived
 rec = json.loads(bench_line)
-fpl = rec["config"].get("frames_per_launch", 1)
+fpl = int(round(rec["config"].get("frames_per_launch", 1)))
 rays = W * H * fpl                            # per launch
 lines.append("## derived")
 if "GRBM_GUI_ACTIVE" in counters:
