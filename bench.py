@@ -218,6 +218,9 @@ def main():
     # output is the frame-at-a-time figure (the reference's own call pattern).
     batch = args.frames_per_launch or 16
     batch = max(1, min(32, batch))
+    # the timed run's launch size is the warm-up's too (20 steps at up to 16 per launch: 10 and 10, and the
+    # warm-up's launches hold 10): a launch learns its tile order and its grid from the launch before it
+    batch = -(-args.steps // -(-args.steps // batch)) if args.steps > 0 else batch
     if world > 1:
         # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
         # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), the frames of a launch

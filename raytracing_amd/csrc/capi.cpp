@@ -215,7 +215,8 @@ unsigned render_blocks(const rm_ctx* c, bool jit, size_t frames) {
         if (std::atoi(env) > 0) per_cu = static_cast<size_t>(std::atoi(env));
     size_t resident = static_cast<size_t>(c->cus) * per_cu;
     if (!std::getenv("RM_BLOCKS_PER_CU") && c->adaptive_grid) {
-        const size_t by_work = (wanted_waves(c, tiles) + 3) / 4;
+        const size_t waves = wanted_waves(c, tiles);                     // ~0 when nothing has been measured yet
+        const size_t by_work = waves > 4 * resident ? resident : (waves + 3) / 4;
         const size_t floor = static_cast<size_t>(c->cus) * 2;            // never below two workgroups per CU
         if (by_work < resident) resident = by_work > floor ? by_work : floor;
     }

@@ -479,9 +479,14 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         if (in_image) {                                                            // :717
             const uint32_t hit = shaded >> 8;
             uint32_t pixel = 0xff000000u;                                          // :622
-            if (hit) {                                                             // :695-699
-                const float L = (float)(shaded & 0xffu);
-                pixel = to_u8(L * RM_MATERIAL_R) | (to_u8(L * RM_MATERIAL_G) << 8) | (to_u8(L * RM_MATERIAL_B) << 16) | 0xff000000u;
+            // (most tiles hold no shaded pixel at all: one scalar test, no arithmetic)
+            if (__builtin_amdgcn_ballot_w64(hit != 0) != 0 && hit) {               // :695-699
+                // L is a whole number in [0, 255] and the material factors lie in (0, 1]: the casts of :697-699
+                // need no saturation here, and the blue channel is L itself
+                static_assert(RM_MATERIAL_R > 0.f && RM_MATERIAL_R <= 1.f && RM_MATERIAL_G > 0.f && RM_MATERIAL_G <= 1.f, "");
+                const uint32_t Lu = shaded & 0xffu;
+                const float L = (float)Lu;
+                pixel = (uint32_t)(int)(L * RM_MATERIAL_R) | ((uint32_t)(int)(L * RM_MATERIAL_G) << 8) | (Lu << 16) | 0xff000000u;
             }
             KernargParams* ep = kernarg_params();
             *reinterpret_cast<uint32_t*>(ep->rgba + frame * ep->frame_stride + (size_t)ly * ep->pitch + (size_t)px * 4) = pixel;
