@@ -127,11 +127,14 @@ __device__ __forceinline__ P3 movo(P3 p, float tx, float ty, float tz) { return 
 __device__ __forceinline__ P3 rotx(P3 p, float c, float s) { return P3{p.x, c * p.y + s * p.z, -s * p.y + c * p.z}; }
 __device__ __forceinline__ P3 roty(P3 p, float c, float s) { return P3{-s * p.z + c * p.x, p.y, c * p.z + s * p.x}; }
 __device__ __forceinline__ P3 rotz(P3 p, float c, float s) { return P3{c * p.x + s * p.y, -s * p.x + c * p.y, p.z}; }
+// p + 2 * s (:527-530, :567-569) as one fma: 2 * s is exact in binary floating point (inf stays inf, denormals
+// double exactly), so fma(2, s, p) rounds the same sum once, as the reference's multiply and add do
+__device__ __forceinline__ float plus_twice(float p, float s) { return __builtin_fmaf(2.f, s, p); }
 __device__ __forceinline__ P3 rotq(P3 p, float xx, float xy, float xz, float yx, float yy, float yz,
                                    float zx, float zy, float zz) {
-    return P3{p.x + 2.f * (xx * p.x + xy * p.y + xz * p.z),
-              p.y + 2.f * (yx * p.x + yy * p.y + yz * p.z),
-              p.z + 2.f * (zx * p.x + zy * p.y + zz * p.z)};
+    return P3{plus_twice(p.x, xx * p.x + xy * p.y + xz * p.z),
+              plus_twice(p.y, yx * p.x + yy * p.y + yz * p.z),
+              plus_twice(p.z, zx * p.x + zy * p.y + zz * p.z)};
 }
 // ripeto_t: generated code names the components of `a` that are zero.  Such a one adds +-0 to the dot product and takes
 // N * 0 = +-0 off its coordinate (positions and N are finite): without its terms a result can
@@ -178,9 +181,9 @@ __device__ __forceinline__ P3 roty_back(P3 n, float c, float s) { return P3{s * 
 __device__ __forceinline__ P3 rotz_back(P3 n, float c, float s) { return P3{c * n.x - s * n.y, s * n.x + c * n.y, n.z}; }
 __device__ __forceinline__ P3 rotq_back(P3 n, float xx, float xy, float xz, float yx, float yy, float yz,
                                         float zx, float zy, float zz) {
-    return P3{n.x + 2.f * (xx * n.x + yx * n.y + zx * n.z),
-              n.y + 2.f * (xy * n.x + yy * n.y + zy * n.z),
-              n.z + 2.f * (xz * n.x + yz * n.y + zz * n.z)};
+    return P3{plus_twice(n.x, xx * n.x + yx * n.y + zx * n.z),
+              plus_twice(n.y, xy * n.x + yy * n.y + zy * n.z),
+              plus_twice(n.z, xz * n.x + yz * n.y + zz * n.z)};
 }
 __device__ __forceinline__ P3 neg3(P3 n) { return P3{-n.x, -n.y, -n.z}; }
 
