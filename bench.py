@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--no-single-frame", action="store_true", help="skip the extra frame-per-launch measurement (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=0, help="contexts taking launches in turn (0 = 1 for N=1, 3 for N>1)")
     ap.add_argument("--frames-per-launch", type=int, default=0,
-                    help="most frames whose tiles one launch pools (rm_set_batch), 1..32; 0 = 16")
+                    help="most frames whose tiles one launch pools (rm_set_batch), 1..32; 0 = 16 on one GPU, 32 on several")
     ap.add_argument("--warmup-seconds", type=float, default=0.25,
                     help="warm up for at least this long as well as for --warmup frames (clocks, tile order)")
     args = ap.parse_args()
@@ -216,11 +216,16 @@ def main():
     # tiles of the others.  At N>1 it is what makes a rank's launch worth launching: an 8-rank share of ONE frame
     # is too little work to fill the chip for as long as its longest ray marches.  `single_frame_launch` in the
     # output is the frame-at-a-time figure (the reference's own call pattern).
-    batch = args.frames_per_launch or 16
+    # N>1: up to 32, so that a rank's launch at N=8 holds four frames' worth of tiles (tools/slice_rate.py, render
+    # side only, 3 contexts in flight: 48 k shares/s per GPU at 4K against 6.4 k whole frames/s on one GPU, 11.1 k
+    # against 1.43 k at 8K), and at least two launches, so that a gather runs under the next launch's kernel.
+    batch = args.frames_per_launch or (16 if world == 1 else 32)
     batch = max(1, min(32, batch))
     # the timed run's launch size is the warm-up's too (20 steps at up to 16 per launch: 10 and 10, and the
     # warm-up's launches hold 10): a launch learns its tile order and its grid from the launch before it
-    batch = -(-args.steps // -(-args.steps // batch)) if args.steps > 0 else batch
+    if args.steps > 0:
+        n_launches = max(-(-args.steps // batch), min(2, args.steps) if world > 1 else 1)
+        batch = -(-args.steps // n_launches)
     if world > 1:
         # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
         # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), the frames of a launch
