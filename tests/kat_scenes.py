@@ -145,3 +145,90 @@ def points(count=192, seed=7, span=12.0):
         [0.5, 0.25, 0.125], [7, 1, 2], [3.5, 0.5, 1], [10.5, 1.5, 3], [1e-3, -1e-3, 1e-3], [100, -200, 300],
     ], dtype=np.float32)
     return np.concatenate([pts, near, special])
+
+
+# Hand-derived known answers: values worked out on paper from the formulas in the reference's source text
+# (Source/cuda_kernels.cu, the lines cited per case), with payloads and points chosen so that every
+# intermediate is exact in fp32 (small dyadic numbers, Pythagorean triples).  They pin the restatement - and
+# through it the device evaluators - for the node types neither stock scene uses, against something that is not
+# the restatement itself.  (tree, point, DIST, NORM unnormalised); a string "sqrt:x" stands for float32(sqrt(x)).
+_E124 = ("ebeno", (1, 2, 4))
+_EX, _EY = ("ebeno", (1, 0, 0)), ("ebeno", (0, 1, 0))
+_S1 = ("sfero", (1,))
+_XP, _XM, _YP, _YM = (("movo", t, _S1) for t in ((6, 0, 0), (-6, 0, 0), (0, 6, 0), (0, -6, 0)))
+ANALYTIC = [
+    # sfero :72-79: |p| - r; the normal is p itself
+    (S5, (3, 4, 12), 8.0, (3, 4, 12)),
+    # kubo :81-105, b = (3,4,5).  Inside: the largest of q = |p| - b; axis picked by q.x>q.z ? (q.x>q.y ? X : Y) : ..., sign p>0 ? 1 : -1
+    (K345, (0, 0, 0), -3.0, (-1, 0, 0)),
+    (K345, (1, 3.5, -1), -0.5, (0, 1, 0)),
+    (K345, (2, 0, -4.75), -0.25, (0, 0, -1)),
+    # outside: |max(q,0)|; per axis q>0 ? sign : 0
+    (K345, (6, 8, 5), 5.0, (1, 1, 0)),
+    (K345, (-6, 0, 0), 3.0, (-1, 0, 0)),
+    (K345, (-5, 10, 8), "sqrt:49", (-1, 1, 1)),            # q = (2,6,3): 4+36+9
+    # cilindro :107-127, r = 3, h = 4: q = (hypot(p.x,p.y) - r, |p.z| - h)
+    (C34, (3, 4, 0), 2.0, (3, 4, 0)),                       # q = (2,-4): hypot(2,0); q.x > q.y: radial normal
+    (C34, (0, 0, 10), 6.0, (0, 0, 1)),                      # q = (-3,6)
+    (C34, (0, 0, 0), -3.0, (0, 0, 0)),                      # inside, q = (-3,-4): the larger; q.x > q.y: (p.x,p.y,0)
+    (C34, (0, 0, -1), -3.0, (0, 0, -1)),                    # q = (-3,-3): a tie goes to the cap
+    (C34, (6, 8, 7), "sqrt:58", (6, 8, 0)),                 # q = (7,3)
+    (C34, (0, 5, -6), "sqrt:8", (0, 0, -1)),                # q = (2,2): tie, cap; p.z > 0 ? 1 : -1
+    # ebeno :129-136: dot(n,p), normal n
+    (("ebeno", (0.5, 0.25, 0.75)), (2, 4, 8), 8.0, (0.5, 0.25, 0.75)),
+    (_E124, (-2, 0, 0.25), -1.0, (1, 2, 4)),
+    # komplemento :336-347, movo :406-423
+    (("komplemento", (), S5), (3, 4, 12), -8.0, (-3, -4, -12)),
+    (("movo", (1, 2, 3), _E124), (2, 4, 6), 17.0, (1, 2, 4)),
+    # rotations by stored cos/sin (not required to be a rotation: c = .5, s = .25 keeps everything exact)
+    # rotacioX :425-447: P.y = c y + s z, P.z = -s y + c z; normal back with (c,-s; s,c)
+    (("rotacioX", (0.5, 0.25), _E124), (1, 2, 4), 11.0, (1, 0, 2.5)),
+    (("rotacioX", (0, 1), ("kubo", (1, 2, 3))), (0, 0, 10), 8.0, (0, 0, 1)),
+    # rotacioY :449-471: P.z = c z + s x, P.x = -s z + c x
+    (("rotacioY", (0.5, 0.25), _E124), (1, 2, 4), 12.5, (1.5, 2, 1.75)),
+    # rotacioZ :473-495: P.x = c x + s y, P.y = -s x + c y
+    (("rotacioZ", (0.5, 0.25), _E124), (1, 2, 4), 18.5, (0, 1.25, 4)),
+    # rotacioQ :497-571 with q_w = .5, q = (.5,.5,.5): Q = ((-.5,0,.5),(.5,-.5,0),(0,.5,-.5)), P = p + 2 Q p = (z,x,y)
+    (("rotacioQ", (0.5, 0.5, 0.5, 0.5), ("kubo", (1, 2, 3))), (10, 0, 0), 8.0, (1, 0, 0)),
+    (("rotacioQ", (0.5, 0.5, 0.5, 0.5), _E124), (1, 2, 3), 13.0, (2, 4, 1)),       # P = (3,1,2): 3+2+8; N + 2 Q^T N
+    # senfina_ripeto :573-592, a = (4,0,0): N = floor(dot(a,p)/dot(a,a) + .5)
+    (("senfina_ripeto", (4, 0, 0), _S1), (8, 3, 4), 4.0, (0, 3, 4)),
+    (("senfina_ripeto", (4, 0, 0), _S1), (6, 0, 0), 1.0, (-2, 0, 0)),              # 1.5 + .5 = 2: the cell boundary goes up
+    (("senfina_ripeto", (4, 0, 0), _S1), (-9, 0, 0), 0.0, (-1, 0, 0)),             # floor(-2.25 + .5) = -2
+    # portanta_sfero :51-70, t = (1,2,3), r = 6: outside the sphere its distance, within RAYS_MIN_DIST of it the child
+    (("portanta_sfero", (1, 2, 3, 6), ("kubo", (2, 2, 2))), (1, 2, 13), 4.0, (0, 0, 1)),
+    (("portanta_sfero", (1, 2, 3, 6), ("kubo", (2, 2, 2))), (1, 2, 8), 3.0, (0, 0, 1)),
+    # kunigajo :138-235: min; the normal's child: _2 takes o1 unless d0 < d1, _3/_4 move on only on strict >
+    (("kunigajo_2", (), _XP, _XM), (0, 0, 0), 5.0, (6, 0, 0)),
+    (("kunigajo_2", (), _XP, _XM), (1, 0, 0), 4.0, (-5, 0, 0)),
+    (("kunigajo_3", (), _XP, _XM, _YP), (0, 0, 0), 5.0, (-6, 0, 0)),
+    (("kunigajo_4", (), _XP, _XM, _YP, _YM), (0, 0, 0), 5.0, (-6, 0, 0)),
+    (("kunigajo_4", (), _XP, _XM, _YP, _YM), (0, -2, 0), 3.0, (0, 4, 0)),
+    (("kunigajo_3", (), _XP, _XM, _YP), (0, 3, 0), 2.0, (0, -3, 0)),
+    # komunajo :237-334: max; _2 takes o1 unless d0 > d1, _3/_4 move on only on strict <
+    (("komunajo_2", (), _XP, _XM), (0, 0, 0), 5.0, (6, 0, 0)),
+    (("komunajo_2", (), _XP, _XM), (-1, 0, 0), 6.0, (-7, 0, 0)),
+    (("komunajo_3", (), _XP, _XM, _YP), (0, 0, 0), 5.0, (-6, 0, 0)),
+    (("komunajo_4", (), _XP, _XM, _YP, _YM), (0, 0, 0), 5.0, (-6, 0, 0)),
+    (("komunajo_4", (), _XP, _XM, _YP, _YM), (1, 0, 0), 6.0, (7, 0, 0)),
+    (("komunajo_3", (), _XP, _XM, _YP), (0, -3, 0), 8.0, (0, -9, 0)),
+    # glata_kunigajo_2 :349-375, k = 2 over the planes x and y: h = (1 - (d0-d1)/k)/2; h > 1: d0, h < 0: d1,
+    # else mix(d0,d1,h) - k h (1-h) with mix(a,b,x) = a + x (b - a); normal: the same gates, else the mix of the unit normals
+    (("glata_kunigajo_2", (2,), _EX, _EY), (1, 2, 0), 1.375, (0.25, 0.75, 0)),
+    (("glata_kunigajo_2", (2,), _EX, _EY), (0, 8, 0), 0.0, (1, 0, 0)),
+    (("glata_kunigajo_2", (2,), _EX, _EY), (8, 0, 0), 0.0, (0, 1, 0)),
+    # glata_komunajo_2 :377-403: h = (1 + (d0-d1)/k)/2, + k h (1-h)
+    (("glata_komunajo_2", (2,), _EX, _EY), (1, 2, 0), 1.625, (0.75, 0.25, 0)),
+    (("glata_komunajo_2", (2,), _EX, _EY), (8, 0, 0), 8.0, (1, 0, 0)),
+    (("glata_komunajo_2", (2,), _EX, _EY), (0, 8, 0), 8.0, (0, 1, 0)),
+]
+
+
+def analytic_cases():
+    """[(table, point float32[3], dist float32, norm float32[3])]"""
+    out = []
+    for tree, p, d, n in ANALYTIC:
+        if isinstance(d, str):
+            d = np.sqrt(np.float32(float(d.split(":")[1])), dtype=np.float32)
+        out.append((Tree(tree).table(), np.array(p, dtype=np.float32), np.float32(d), np.array(n, dtype=np.float32)))
+    return out

@@ -115,6 +115,27 @@ def test_node_kat(name):
     assert same_floats(n_jit, want_n), "generated code NORM differs from the oracle"
 
 
+def test_hand_derived_known_answers():
+    """The hand-derived closed forms of kat_scenes.ANALYTIC (worked out from the reference's source text, exact
+    in fp32) on every device evaluator: the device against the paper, not against the oracle."""
+    for i, (table, p, want_d, want_n) in enumerate(kat_scenes.analytic_cases()):
+        with api.Raymarching(64, 64) as rm:
+            rm.set_jit(2)
+            rm.set_nodes(table)
+            pts = p.reshape(1, 3)
+            got = {"program": (rm.eval_points(pts, 0, which=0, want_norm=False)[0], None),
+                   "walker": rm.eval_points(pts, 0, which=1, want_norm=True),
+                   "generated": rm.eval_points(pts, 0, which=2, want_norm=True)}
+            rm.set_jit(3)
+            rm.set_nodes(table)
+            got["compiled program"] = rm.eval_points(pts, 0, which=2, want_norm=True)
+        for name, (d, n) in got.items():
+            label = "case %d (%s at %s) on the %s" % (i, kat_scenes.ANALYTIC[i][0][0], p, name)
+            assert same_floats(d, [want_d]), "%s: DIST %r, by hand %r" % (label, d, want_d)
+            if n is not None:
+                assert same_floats(n[0], want_n), "%s: NORM %s, by hand %s" % (label, n[0], want_n)
+
+
 def test_node_kat_inner_nodes():
     """The walker can start at any reachable node (sub-tree evaluation)."""
     table = kat_scenes.tables()["nested_frames"]

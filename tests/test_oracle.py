@@ -56,6 +56,20 @@ def test_pinned_by_reference_counts_1080p(stock_scenes, name):
         assert zlib.decompress(f.read()) == packed
 
 
+def test_hand_derived_known_answers():
+    """DIST and NORM at points where the reference's formulas (Source/cuda_kernels.cu:51-592, cited per case in
+    kat_scenes.ANALYTIC) have exact closed forms worked out by hand: every node type, both gates of the smooth
+    combinators, every tie rule of the normals.  The one check of the restatement against something that is neither
+    itself nor the survey's hashes - and the only one for the node types the stock scenes do not use."""
+    cases = kat_scenes.analytic_cases()
+    assert {kat_scenes.ANALYTIC[i][0][0] for i in range(len(cases))} == set(O.TYPE_NAMES)
+    for i, (table, p, want_d, want_n) in enumerate(cases):
+        got_d = np.float32(O.dist(table, 0, p))
+        got_n = np.array(O.norm(table, 0, p), dtype=np.float32)
+        assert got_d == want_d, "case %d (%s at %s): DIST %r, by hand %r" % (i, kat_scenes.ANALYTIC[i][0][0], p, got_d, want_d)
+        assert np.array_equal(got_n, want_n), "case %d (%s at %s): NORM %s, by hand %s" % (i, kat_scenes.ANALYTIC[i][0][0], p, got_n, want_n)
+
+
 def test_node_kat_fixture(golden_dir):
     """Node-level known answers frozen in node_kat.npz still hold (compiler / edit drift)."""
     kat = np.load(os.path.join(golden_dir, "node_kat.npz"))
