@@ -310,16 +310,18 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         while (m_p | m_s) {
             P3 at;
             typename Scene::Keep keep;
-            // The trips of a tile whose marching lanes are all in one phase and none at a surface.  A trip that
-            // is anything else leaves this loop evaluated (trips, at, cd, keep) and the general tail finishes it.
-            for (;;) {
-                ++trips;
-                // DIST(root, pos) for the whole wave (:627 and :661 share this)
-                at = pos;
-                cd = scene.dist_keep(at, scratch, m_p | m_s, keep);       // every lane: nothing reads a resting lane's value
-                if (m_s == 0) {
-                    // ---- primary lanes only (:707-714); at a surface: cd < RM_MIN_DIST (:629)
-                    if (__builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p) break;
+            // The trips of a tile whose marching lanes are all in one phase and none at a surface run in a loop of
+            // their phase's own (two loops, each with the scene's distance code in it: in one loop with a branch on
+            // the phase the compiler carries the shadow phase's position, distance and shadow term in registers of
+            // their own and copies them back and forth every trip, ten moves of 120 instructions).  A trip that is
+            // anything else leaves its loop evaluated (trips, at, cd, keep) and the general tail finishes it.
+            if (m_s == 0) {
+                // ---- primary lanes only (:707-714)
+                for (;;) {
+                    ++trips;
+                    at = pos;
+                    cd = scene.dist_keep(at, scratch, m_p, keep);             // DIST(root, pos) for the whole wave (:627): nothing reads a resting lane's value
+                    if (__builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p) break;        // at a surface (:629)
                     asm volatile("" ::: "memory");         // two scalar branches: merged, the compiler evaluates the pair as lane masks
                     if (trips >= due) break;
                     if (lanes(m_p)) {
@@ -328,9 +330,14 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     }
                     m_p &= ~__builtin_amdgcn_ballot_w64(t >= t_lim);           // a resting lane's stale t clears a bit that is clear
                     if (m_p == 0) break;
-                } else if (m_p == 0) {
-                    // ---- shadow lanes only (:679-690); at a surface: 8 * cd < RM_MIN_DIST (:662)
-                    if (__builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s) break;
+                }
+            } else if (m_p == 0) {
+                // ---- shadow lanes only (:679-690)
+                for (;;) {
+                    ++trips;
+                    at = pos;
+                    cd = scene.dist_keep(at, scratch, m_s, keep);             // :661
+                    if (__builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s) break;    // at a surface (:662)
                     asm volatile("" ::: "memory");
                     if (trips >= next_check) break;
                     // shadow = min(shadow, (128*cd)/t), the division only in a trip in which it can lower some
@@ -358,9 +365,12 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                         m_s &= ~left;
                         if (m_s == 0) break;
                     }
-                } else {
-                    break;
                 }
+            } else {
+                // ---- lanes in both phases: one evaluation serves them all (:627 and :661)
+                ++trips;
+                at = pos;
+                cd = scene.dist_keep(at, scratch, m_p | m_s, keep);
             }
             if ((m_p | m_s) == 0) break;
 
