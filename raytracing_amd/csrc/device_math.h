@@ -61,6 +61,22 @@ __device__ __forceinline__ float div_const(float a, float c, float rc) {
     }
     return q;
 }
+// The quotient of senfina_ripeto (:577) is only ever used as floor(q + .5f).  Below the range div_const proves
+// (|a| < 2^-80, with 2^-20 <= |c|) the IEEE quotient is under 2^-60 and the short sequence's under 2^-50 (no
+// operation of it can produce an infinity or a NaN from a tiny or zero numerator): either way q + .5f rounds
+// to .5f and the floor is +0.  So the guard is one-sided here, one compare with a modifier instead of three
+// instructions - and a lattice takes one to three of these quotients per march step.
+__device__ __forceinline__ float div_const_for_floor(float a, float c, float rc) {
+    if (rc == 0.f) return a / c;                     // wave-uniform: rc is a scene constant
+    float q = a * rc;
+    q = __builtin_fmaf(__builtin_fmaf(-c, q, a), rc, q);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(fabsf(a) < 0x1p80f)) != 0, 0)) {      // also NaN
+        float as = a;
+        asm volatile("; div_const_for_floor: IEEE path" : "+v"(as));
+        q = as / c;
+    }
+    return q;
+}
 __device__ __forceinline__ float min2(float a, float b) { return (b < a) ? b : a; }   // std::min
 __device__ __forceinline__ float max2(float a, float b) { return (a < b) ? b : a; }   // std::max
 // Include/cuda_defines.cuh:49-53
@@ -150,7 +166,7 @@ __device__ __forceinline__ P3 ripeto_t(P3 p, float ax, float ay, float az, float
     else if (ZY) dot = ax * p.x + az * p.z;
     else if (ZZ) dot = ax * p.x + ay * p.y;
     else dot = dot3(ax, ay, az, p.x, p.y, p.z);
-    float N = floorf(div_const(dot, aa, raa) + .5f);
+    float N = floorf(div_const_for_floor(dot, aa, raa) + .5f);
     return P3{ZX ? p.x : p.x - N * ax, ZY ? p.y : p.y - N * ay, ZZ ? p.z : p.z - N * az};
 }
 __device__ __forceinline__ P3 ripeto(P3 p, float ax, float ay, float az, float aa, float raa) {

@@ -113,7 +113,7 @@ verify_sqrt_kernel(uint32_t first, unsigned long long count, unsigned long long*
     if (mine) atomicAdd(bad, mine);
 }
 
-// div_const against IEEE division.  blockIdx.y picks the divisor; numerators are `count`
+// div_const (and floor(div_const_for_floor + .5)) against IEEE division.  blockIdx.y picks the divisor; numerators are `count`
 // consecutive bit patterns from `first` (one binade, [1,2), proves a divisor: device_math.h)
 __global__ void __launch_bounds__(256)
 verify_div_kernel(const float* __restrict__ c, const float* __restrict__ rc, uint32_t first, unsigned long long count,
@@ -125,6 +125,9 @@ verify_div_kernel(const float* __restrict__ c, const float* __restrict__ rc, uin
         const float a = as_f(first + (uint32_t)i);
         const float want = a / cc, got = div_const(a, cc, rr);
         if (as_u(want) != as_u(got) && !(want != want && got != got)) ++mine;
+        // and the lattice's one-sidedly guarded variant, in the only form its result is used in (:577)
+        const float wantN = floorf(want + .5f), gotN = floorf(div_const_for_floor(a, cc, rr) + .5f);
+        if (as_u(wantN) != as_u(gotN) && !(wantN != wantN && gotN != gotN)) ++mine;
     }
     if (mine) atomicAdd(bad + blockIdx.y, mine);
 }

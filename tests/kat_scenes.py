@@ -195,6 +195,9 @@ ANALYTIC = [
     (("senfina_ripeto", (4, 0, 0), _S1), (8, 3, 4), 4.0, (0, 3, 4)),
     (("senfina_ripeto", (4, 0, 0), _S1), (6, 0, 0), 1.0, (-2, 0, 0)),              # 1.5 + .5 = 2: the cell boundary goes up
     (("senfina_ripeto", (4, 0, 0), _S1), (-9, 0, 0), 0.0, (-1, 0, 0)),             # floor(-2.25 + .5) = -2
+    (("senfina_ripeto", (4, 0, 0), _S1), (0, 0, 0), -1.0, (0, 0, 0)),              # numerators at and near zero: N = 0
+    (("senfina_ripeto", (4, 0, 0), _S1), (1e-30, 0, 0), -1.0, (1e-30, 0, 0)),
+    (("senfina_ripeto", (4, 0, 0), _S1), (-1e-42, 3, 4), 4.0, (-1e-42, 3, 4)),     # a denormal coordinate
     # portanta_sfero :51-70, t = (1,2,3), r = 6: outside the sphere its distance, within RAYS_MIN_DIST of it the child
     (("portanta_sfero", (1, 2, 3, 6), ("kubo", (2, 2, 2))), (1, 2, 13), 4.0, (0, 0, 1)),
     (("portanta_sfero", (1, 2, 3, 6), ("kubo", (2, 2, 2))), (1, 2, 8), 3.0, (0, 0, 1)),
