@@ -372,8 +372,12 @@ int upload_scene(rm_ctx* c, const rm_node* nodes, size_t n) {
         (void)hipFree(d_prog); (void)hipFree(d_tree);
         return RM_ERR_TOO_LARGE;
     }
+    if (c->jit.module) {                              // the previous scene's kernels: nothing of them in flight, then let go
+        (void)hipStreamSynchronize(c->stream);
+        rm::jit_release(c->jit);
+    }
     c->jit_active = jit_ok;
-    c->jit = jit;
+    c->jit = jit_ok ? jit : rm::JitKernels();
 
     if (c->d_program) (void)hipFree(c->d_program);
     if (c->d_tree) (void)hipFree(c->d_tree);
@@ -495,6 +499,8 @@ int rm_destroy(rm_ctx* c) {
     if (!c) return RM_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->stream && c->stream != c->own_stream) (void)hipStreamSynchronize(c->stream);
+    rm::jit_release(c->jit);
     if (c->d_program) (void)hipFree(c->d_program);
     if (c->d_tree) (void)hipFree(c->d_tree);
     if (c->fb) (void)hipFree(c->fb);

@@ -875,7 +875,25 @@ struct CacheKey {
     bool operator<(const CacheKey& o) const { return device != o.device ? device < o.device : hash < o.hash; }
 };
 std::mutex g_mutex;
-std::map<CacheKey, JitKernels> g_cache;      // modules live until the process ends
+// Loaded code objects by (device, source hash).  An entry counts the contexts that run it; one that no context
+// runs any more stays until kCacheIdle such entries have piled up, then the least recently used ones are unloaded
+// (a host that edits its scene every frame would otherwise keep a code object per edit until the process ends).
+struct CacheEntry { JitKernels k; int refs = 0; uint64_t used = 0; };
+constexpr size_t kCacheIdle = 32;
+uint64_t g_clock = 0;
+std::map<CacheKey, CacheEntry> g_cache;
+
+void trim_cache() {          // g_mutex held
+    for (;;) {
+        size_t idle = 0;
+        auto oldest = g_cache.end();
+        for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+            if (it->second.refs == 0) { ++idle; if (oldest == g_cache.end() || it->second.used < oldest->second.used) oldest = it; }
+        if (idle <= kCacheIdle) return;
+        if (oldest->second.k.module) (void)hipModuleUnload(oldest->second.k.module);
+        g_cache.erase(oldest);
+    }
+}
 
 hipError_t load_module(const std::vector<char>& code, size_t lds_bytes, JitKernels* out) {
     out->lds_bytes = lds_bytes;
@@ -957,7 +975,7 @@ hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_b
 
     std::lock_guard<std::mutex> lock(g_mutex);
     auto it = g_cache.find(CacheKey{device, hash});
-    if (it != g_cache.end()) { *out = it->second; return hipSuccess; }
+    if (it != g_cache.end()) { ++it->second.refs; it->second.used = ++g_clock; *out = it->second.k; return hipSuccess; }
 
     std::vector<char> code;
     const std::string path = disk_path(hash, arch);
@@ -1001,9 +1019,19 @@ hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_b
     }
     e = load_module(code, lds_bytes, &k);
     if (e != hipSuccess) { if (k.module) (void)hipModuleUnload(k.module); return e; }
-    g_cache[CacheKey{device, hash}] = k;
+    CacheEntry& entry = g_cache[CacheKey{device, hash}];
+    entry.k = k; entry.refs = 1; entry.used = ++g_clock;
     *out = k;
+    trim_cache();
     return hipSuccess;
+}
+
+void jit_release(const JitKernels& k) {
+    if (!k.module) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto& kv : g_cache)
+        if (kv.second.k.module == k.module) { if (kv.second.refs > 0) --kv.second.refs; break; }
+    trim_cache();
 }
 
 hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, unsigned blocks, hipStream_t stream) {

@@ -59,6 +59,10 @@ bool jit_build_code(const std::string& arch, const std::string& source, std::vec
 // Returns hipSuccess, or an error with the compiler log in *log.
 hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_bytes, JitKernels* out, std::string* log);
 
+// A context is done with kernels it got from jit_compile (none of them may be running any more): the code
+// object may be unloaded once enough others have come and gone.
+void jit_release(const JitKernels& k);
+
 hipError_t jit_launch_render(const JitKernels& k, const RenderParams& prm, unsigned blocks, hipStream_t stream);
 hipError_t jit_launch_eval_points(const JitKernels& k, const RenderParams& prm, const float* xyz, uint32_t count,
                                   float* dist_out, float* norm_out, hipStream_t stream);
