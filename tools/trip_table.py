@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""trip_table.py SCENE [out.txt]: the march loop of a scene's generated kernel (8-wave build, compiled offline
-for gfx950), instruction by instruction and by class, against the algorithmic FLOPs of one trip.  No GPU needed.
-The loop is found as the innermost loop of the assembly that holds the lattice's v_floor_f32 (chair.sce,
-infinity.sce) or, failing that, the first v_rsq_f32; blocks the compiler placed behind the loop (the IEEE
-fall-backs of the short sqrt and quotient) are not part of it."""
+"""trip_table.py SCENE [out.txt]: the march loops of a scene's generated kernel (8-wave build, compiled offline
+for gfx950), instruction by instruction and by class.  No GPU needed.  The loops are the innermost loops of the
+assembly that evaluate the scene (a v_floor_f32 or v_rsq_f32 in them): one for primary-only trips, one for
+shadow-only trips; blocks the compiler placed behind a loop (the IEEE fall-backs of the short sqrt and quotient)
+are not counted."""
 import os
 import re
 import subprocess
@@ -25,17 +25,16 @@ subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off",
 lines = open(asm).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("rm_render_jit:"))
 end = next(i for i, l in enumerate(lines) if i > start and l.strip().startswith(".Lfunc_end"))
-labels = {m.group(1): i for i, l in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
-loops = []
+# the compiler marks innermost loop headers; a loop's body is taken from its header to the last branch back to
+# that header (the IEEE fall-backs of the short sqrt and quotient are placed behind it and jump back into it)
+inner = []
 for i in range(start, end):
-    m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", lines[i])
-    if m and labels.get(m.group(1), i) < i:
-        loops.append((labels[m.group(1)], i))
-key = "v_floor_f32" if any("v_floor_f32" in l for l in lines[start:end]) else "v_rsq_f32"
-cands = [(a, b) for a, b in loops if any(key in l for l in lines[a:b])]
-a, b = min(cands, key=lambda ab: ab[1] - ab[0])
-# widen to the outermost back-edge of the same header (the loop's several latches)
-b = max(bb for aa, bb in loops if aa == a)
+    m = re.match(r"^(\.LBB\d+_\d+):", lines[i])
+    if not m or not any("This Inner Loop Header" in l for l in lines[i:i + 4]):
+        continue
+    back = [j for j in range(i, end) if re.search(r"s_c?branch\w*\s+" + re.escape(m.group(1)) + r"\s*$", lines[j])]
+    if back and any("v_floor_f32" in l or "v_rsq_f32" in l for l in lines[i:back[-1]]) and back[-1] - i > 30:
+        inner.append((i, back[-1]))
 
 
 def klass(op):
@@ -64,26 +63,29 @@ def klass(op):
     return "memory / other"
 
 
-counts, listing = {}, []
-for l in lines[a:b + 1]:
-    t = l.strip()
-    if not t or t.startswith((";", ".")) and not re.match(r"^\.LBB", t):
-        continue
-    if re.match(r"^\.LBB", t):
-        listing.append(t.split(";")[0].strip())
-        continue
-    op = t.split()[0]
-    k = klass(op)
-    counts[k] = counts.get(k, 0) + 1
-    listing.append("    %-58s ; %s" % (t.split(";")[0].strip()[:58], k))
-vec = sum(v for k, v in counts.items() if not k.startswith(("scalar", "memory")))
-text = ["# %s.sce: the march loop of the generated kernel, 8-wave build (hipcc offline, gfx950), lines %d-%d of the assembly" % (name, a, b),
-        "# every instruction inside the loop's outermost back-edge, ALL paths together (primary trips, shadow trips, the",
-        "# general tail, the carved-out solids behind their bound): a trip executes one path through it", ""]
-for k, v in sorted(counts.items(), key=lambda kv: -kv[1]):
-    text.append("%-62s %5d" % (k, v))
-text += ["%-62s %5d" % ("vector instructions, all paths", vec), "", "## listing"] + listing
+text = ["# %s.sce: the march loops of the generated kernel, 8-wave build (hipcc offline, gfx950)" % name,
+        "# every instruction inside each loop's outermost back-edge, ALL its paths together (e.g. the carved-out solids",
+        "# behind their bound, the shadow quotient behind its test): a trip executes one path through it", ""]
+for a, b in inner:
+    counts, listing = {}, []
+    for l in lines[a:b + 1]:
+        t = l.strip()
+        if not t or t.startswith((";", ".")) and not re.match(r"^\.LBB", t):
+            continue
+        if re.match(r"^\.LBB", t):
+            listing.append(t.split(";")[0].strip())
+            continue
+        op = t.split()[0]
+        k = klass(op)
+        counts[k] = counts.get(k, 0) + 1
+        listing.append("    %-58s ; %s" % (t.split(";")[0].strip()[:58], k))
+    vec = sum(v for k, v in counts.items() if not k.startswith(("scalar", "memory")))
+    what = "shadow-only trips" if any("v_div_fixup" in l for l in lines[a:b + 1]) else "primary-only trips"
+    text.append("## loop of the %s, lines %d-%d of the assembly" % (what, a, b))
+    for k, v in sorted(counts.items(), key=lambda kv: -kv[1]):
+        text.append("%-62s %5d" % (k, v))
+    text += ["%-62s %5d" % ("vector instructions, all paths", vec), "", "### listing"] + listing + [""]
 out = sys.argv[2] if len(sys.argv) > 2 else None
 if out:
     open(out, "w").write("\n".join(text) + "\n")
-print("\n".join(text[:len(counts) + 6]))
+print("\n".join(l for l in text if not l.startswith(("    ", ".LBB"))))
