@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libraymarching_amd.so")
+LIB_PATH = os.environ.get("RM_LIB_PATH") or os.path.join(_HERE, "libraymarching_amd.so")      # RM_LIB_PATH: A/B runs of two builds on one box
 
 NODE_DTYPE = np.dtype([("type", "<u4"), ("o", "<i4", (4,)), ("f", "<f4", (5,))])
 POINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")])

@@ -343,20 +343,21 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     // shadow = min(shadow, (128*cd)/t), the division only in a trip in which it can lower some
                     // lane's shadow, and then for all of them (see the general tail)
                     const float n = RM_HARDNESS * cd, st = shadow * t;
-                    if (__builtin_amdgcn_ballot_w64(!(n > st + fabsf(st) * 4.8e-7f)) & m_s) {
+                    if (__builtin_amdgcn_ballot_w64(!(n > __builtin_fmaf(fabsf(st), 4.8e-7f, st))) & m_s) {
                         if (lanes(m_s)) {
                             float ns = n;
                             asm volatile("; shadow quotient" : "+v"(ns));       // keeps the division behind the branch
                             shadow = min2(shadow, ns / t);
                         }
                     }
-                    bool ends = shadow < 0.01f;
+                    // (:680-690) the three ends as three compares straight into scalar masks: a bool that is or-ed
+                    // together per lane costs a select and a compare more
+                    unsigned long long left = __builtin_amdgcn_ballot_w64(shadow < 0.01f);
                     if (lanes(m_s)) {
                         pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
                         t += cd;
                     }
-                    ends = ends || t >= RM_MAX_DIST || trips >= deadline;
-                    const unsigned long long left = __builtin_amdgcn_ballot_w64(ends) & m_s;
+                    left = (left | __builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST) | __builtin_amdgcn_ballot_w64(trips >= deadline)) & m_s;
                     if (left) {                                                        // :693-701
                         if (lanes(left)) {
                             float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
@@ -451,7 +452,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 // shadow lane needs it, and then for all of them (for the others min() changes nothing):
                 // one scalar branch, no divergence.
                 const float n = RM_HARDNESS * cd, st = shadow * t;
-                if (__builtin_amdgcn_ballot_w64(!(n > st + fabsf(st) * 4.8e-7f)) & go_s) {
+                if (__builtin_amdgcn_ballot_w64(!(n > __builtin_fmaf(fabsf(st), 4.8e-7f, st))) & go_s) {
                     if (lanes(go_s)) {
                         float ns = n;
                         asm volatile("; shadow quotient" : "+v"(ns));           // keeps the division behind the branch
@@ -461,13 +462,12 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 // (:680-690) a lane whose shadow fell below .01 stops before the step, one that marches past
                 // RM_MAX_DIST or has made RM_SHADOW_STEPS steps after it: either way it is shaded now and its
                 // position is dead, so every shadow lane takes the step and the three ends are one mask
-                bool ends = shadow < 0.01f;
+                left_s = __builtin_amdgcn_ballot_w64(shadow < 0.01f);
                 if (lanes(go_s)) {
                     pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
                     t += cd;
                 }
-                ends = ends || t >= RM_MAX_DIST || trips >= deadline;
-                left_s = __builtin_amdgcn_ballot_w64(ends) & go_s;
+                left_s = (left_s | __builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST) | __builtin_amdgcn_ballot_w64(trips >= deadline)) & go_s;
             }
 
             // ---- lanes whose shadow march ended are shaded (:693-701)
