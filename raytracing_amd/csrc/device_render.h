@@ -124,7 +124,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // its own - twice a hang on the device, in two different shapes of this code.  The block waits
     // for the value itself (the compiler does not track memory operations inside an asm, so the
     // result cannot be left in flight); the other wavefronts of the SIMD fill the microsecond, and
-    // cheap tiles take their places four at a time.
+    // cheap tiles take their places RM_QUEUE_CHUNK at a time.
     auto bump = [&](uint32_t counter, uint32_t by) -> uint32_t {
         const uint32_t* base = kernarg_params()->set_cur;
         uint32_t ret, off = counter * 4u, add = by;
