@@ -178,10 +178,17 @@ def main():
     rehearsal = os.environ.get("RM_BENCH_REHEARSAL", "0") == "1"
     if rehearsal:
         local_rank = 0
+    # RM_BENCH_SOLO_GATHER=1 with --gpus 1: the N>1 code path with one rank - bands, luminance planes, launches in
+    # turn on three contexts and a real RCCL gather (of one part, to itself) - so that a one-GPU box can at least
+    # check that the collective takes the tensors this path hands it.  The numbers it prints mean nothing.
+    solo = world == 1 and os.environ.get("RM_BENCH_SOLO_GATHER", "0") == "1"
+    multi = world > 1 or solo
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if solo:
+            os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -195,7 +202,7 @@ def main():
     info = blocks[0:1].copy()
     sweep = blocks if args.workload.endswith("_sweep") else None
     want = None if sweep is not None else golden_frame(scene, w, h)
-    in_flight = args.in_flight or (1 if world == 1 else 3)
+    in_flight = args.in_flight or (1 if not multi else 3)
 
     # one context per frame in flight, each on a stream of its own
     ctxs, streams = [], []
@@ -219,14 +226,14 @@ def main():
     # N>1: up to 32, so that a rank's launch at N=8 holds four frames' worth of tiles (tools/slice_rate.py, render
     # side only, 3 contexts in flight: 48 k shares/s per GPU at 4K against 6.4 k whole frames/s on one GPU, 11.1 k
     # against 1.43 k at 8K), and at least two launches, so that a gather runs under the next launch's kernel.
-    batch = args.frames_per_launch or (16 if world == 1 else 32)
+    batch = args.frames_per_launch or (16 if not multi else 32)
     batch = max(1, min(32, batch))
     # the timed run's launch size is the warm-up's too (20 steps at up to 16 per launch: 10 and 10, and the
     # warm-up's launches hold 10): a launch learns its tile order and its grid from the launch before it
     if args.steps > 0:
-        n_launches = max(-(-args.steps // batch), min(2, args.steps) if world > 1 else 1)
+        n_launches = max(-(-args.steps // batch), min(2, args.steps) if multi else 1)
         batch = -(-args.steps // n_launches)
-    if world > 1:
+    if multi:
         # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
         # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), the frames of a launch
         # in one RCCL gather, and rank 0 rebuilds each RGBA8 frame from the planes of all ranks
@@ -255,12 +262,12 @@ def main():
     for rm in ctxs:                                    # room for `batch` frames per launch, once, before anything is timed
         rm.set_batch(batch, *strides)
     def before_launch(j):
-        if world > 1:
+        if multi:
             streams[j].wait_event(gathered[j])         # context j's slab is free again
 
     def after_launch(j, n):
         """N>1: the launch's luminance planes to rank 0 in one gather, RGBA8 frames rebuilt there."""
-        if world == 1:
+        if not multi:
             return
         rm = ctxs[j]
         rendered[j].record(streams[j])
@@ -291,7 +298,7 @@ def main():
         run.flush()                                    # frames that do not fill a launch
         for rm in ctxs:
             rm.synchronize()                           # also the completeness check: raises on a frame with tiles missing
-        if world > 1:
+        if multi:
             comm_stream.synchronize()
         torch.cuda.synchronize()
 
@@ -306,7 +313,7 @@ def main():
     drain()
     while True:
         more = 1 if time.perf_counter() - t_warm < args.warmup_seconds else 0
-        if world > 1:
+        if multi:
             flag = torch.tensor([more], dtype=torch.int32, device="cpu" if rehearsal else dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             more = int(flag.item())
@@ -316,7 +323,7 @@ def main():
             step(warm + k)
         warm += 4 * batch * in_flight
         drain()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -330,7 +337,7 @@ def main():
     run.flush()                                        # exactly --steps frames: the last launch may hold fewer
     ev1.record(streams[run.last[0]])
     drain()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
@@ -338,10 +345,10 @@ def main():
     # One context: the kernel's average duration (launch to launch on its stream).  With several
     # in flight kernels overlap; the region's time per launch is what counts then.
     kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / launches
-    if world == 1:
+    if not multi:
         frame = frames[run.last[0]][run.last[1]]
 
-    if world > 1:
+    if multi:
         tmax = torch.tensor([secs], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         secs = float(tmax.item())
@@ -362,7 +369,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
                        "scene_nodes": int(len(nodes)), "contexts_in_flight": in_flight, "frames_per_launch": args.steps / launches, "frames_per_launch_max": batch,
-                       "partition": "whole frame" if world == 1 else
+                       "partition": "whole frame" if not multi else
                        "row bands of %d dealt round-robin over %d ranks; the %d frames of a launch gathered together to rank 0 "
                        "as luminance planes (1 B/px, RCCL), RGBA8 frames rebuilt there" % (band, world, batch)},
             "parity": {"hit_pixels": hits, "rgba_sha256": sha,
@@ -383,7 +390,7 @@ def main():
             per_launch = 1.0 / world * args.steps / launches
             achieved = done["counters"]["flops"] * per_launch / (kernel_ms * 1e-3) / 1e12
             reference = want["counters"]["flops"] * per_launch / (kernel_ms * 1e-3) / 1e12
-            traffic = measured_traffic(args.workload, args.steps / launches) if world == 1 else None
+            traffic = measured_traffic(args.workload, args.steps / launches) if not multi else None
             out["roofline"] = {"bound": "valu_fp32", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                                "traffic": traffic["bytes"] if traffic else None,
@@ -405,7 +412,7 @@ def main():
                                           "the count does not see - an upper bound of the work done" if scene == "csg1024" else ""),
                                "hbm": {"achieved": w * h * 4 / world * args.steps / launches / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "bytes_per_ray": 4}}
-        if world == 1 and batch > 1 and not args.no_single_frame:
+        if not multi and batch > 1 and not args.no_single_frame:
             # the same frame one per launch, as the reference's Process() renders it
             with api.Raymarching(w, h, device=local_rank) as one:
                 one.set_nodes(nodes)
@@ -415,14 +422,14 @@ def main():
                 one.synchronize()
                 ms = sorted(one.process() for _ in range(30))[15]
             out["single_frame_launch"] = {"kernel_ms": ms, "Mrays/s": w * h / ms / 1e3}
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, w, h, info, want)
             out["stats"] = ctxs[0].scene_stats()
         print(json.dumps(out), flush=True)
 
     for rm in ctxs:
         rm.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

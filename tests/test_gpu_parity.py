@@ -794,3 +794,24 @@ def test_bench_two_ranks_on_one_gpu(golden_dir):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 13 and rec["launches"] == 4
     assert rec["parity"]["frame_matches_golden"] is True
+
+
+def test_bench_gather_path_over_rccl_with_one_rank(golden_dir):
+    """bench.py's N>1 path with ONE rank and the real collective (RM_BENCH_SOLO_GATHER): bands, luminance planes,
+    three contexts taking launches in turn, an RCCL gather of the one part to itself, the frame rebuilt from it.
+    What a one-GPU box can check of the RCCL leg: that the collective takes the tensors this path hands it and
+    that the golden frame comes out.  Ranks exchanging bytes over xGMI remain untested until an 8-GPU run."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RM_BENCH_SOLO_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "13", "--warmup", "3",
+           "--frames-per-launch", "4", "--workload", "chair_1080p", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 13 and rec["config"]["contexts_in_flight"] == 3
+    assert "row bands" in rec["config"]["partition"]
+    assert rec["parity"]["frame_matches_golden"] is True
