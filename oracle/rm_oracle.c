@@ -552,28 +552,32 @@ static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float 
 int rmo_ray_window(const rm_scene_bound* b, rm_ray r, float* t_end) {
     *t_end = RM_MAX_DIST;
     if (!b || b->kind == RM_BOUND_NONE) return 1;
+    /* the device applies this to the direction before its normalisation (the test is homogeneous in it); here it
+     * gets the normalised one, so |v| is 1 to rounding */
     const float R = b->r + RM_WINDOW_MARGIN;
     const float ocx = r.p.x - b->c[0], ocy = r.p.y - b->c[1], ocz = r.p.z - b->c[2];
     int usable = fmaxf(fmaxf(fabsf(r.p.x), fabsf(r.p.y)), fabsf(r.p.z)) <= RM_WINDOW_MAX_COORD;
     float px = ocx, py = ocy, pz = ocz, qx = r.d.x, qy = r.d.y, qz = r.d.z;
-    float rs = 1.f;
+    const float vv = r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z;
+    float a = vv;
     if (b->kind == RM_BOUND_CYLINDER) {
         const float ux = b->u[0], uy = b->u[1], uz = b->u[2];
-        const float ou = ocx * ux + ocy * uy + ocz * uz, du = r.d.x * ux + r.d.y * uy + r.d.z * uz;
+        const float ou = ocx * ux + ocy * uy + ocz * uz, vu = r.d.x * ux + r.d.y * uy + r.d.z * uz;
         px -= ou * ux; py -= ou * uy; pz -= ou * uz;
-        qx -= du * ux; qy -= du * uy; qz -= du * uz;
-        const float a = qx * qx + qy * qy + qz * qz;
-        usable = usable && a >= RM_WINDOW_MIN_SIN2;
-        rs = 1.f / sqrtf(a);
+        qx -= vu * ux; qy -= vu * uy; qz -= vu * uz;
+        a = qx * qx + qy * qy + qz * qz;
+        usable = usable && a >= RM_WINDOW_MIN_SIN2 * vv;
     }
-    const float inv_a = rs * rs;
+    const float rs = 1.f / sqrtf(a), inv_a = rs * rs;
+    const float len = sqrtf(vv), si = len * rs;
     const float s0 = -(px * qx + py * qy + pz * qz) * inv_a;
     const float wx = px + s0 * qx, wy = py + s0 * qy, wz = pz + s0 * qz;
     const float p2 = wx * wx + wy * wy + wz * wz;
     const float mag = fabsf(ocx) + fabsf(ocy) + fabsf(ocz) + R;
-    const float Re = R + 5e-6f * mag * rs;
+    const float Re = R + 5e-6f * mag * si;
     const float gap = Re * Re - p2;
-    const float leave = s0 + sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f + (RM_WINDOW_SLACK + 5e-6f * mag * inv_a + 2e-6f * fabsf(s0));
+    const float s_leave = s0 + sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f;
+    const float leave = s_leave * len + (RM_WINDOW_SLACK + 5e-6f * mag * (si * si) + 2e-6f * fabsf(s0 * len));
     if (usable && leave < RM_MAX_DIST) *t_end = leave;
     return !(usable && (gap < 0.f || leave < 0.f));
 }

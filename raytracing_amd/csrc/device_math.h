@@ -214,17 +214,28 @@ __device__ __forceinline__ float glata_h(float d0, float d1, float k, float rk, 
     return (komunajo ? (1.f + q) : (1.f - q)) * .5f;
 }
 
-// kernel_SetRays, Source/cuda_kernels.cu:740-760
-__device__ __forceinline__ void make_ray(const Camera& cam, uint32_t width, uint32_t height, int x, int y,
-                                         P3& p, P3& d) {
+// kernel_SetRays, Source/cuda_kernels.cu:740-760, in two steps: the origin p and the direction before its
+// normalisation (s = pos + Depth * Dir, :744-752), then d = rnorm3df(s) * s (:753-755).  The render kernel takes the
+// second step only for tiles in which some ray can come near the scene (device_render.h, ray_window works on s).
+__device__ __forceinline__ void make_ray_raw(const Camera& cam, uint32_t width, uint32_t height, int x, int y,
+                                             P3& p, P3& s) {
     float X = .5f * (float)(2 * x - (int)width + 1);
     float Y = .5f * (float)(2 * y - (int)height + 1);
     float Z = cam.depth;
     P3 pos{X * cam.wvec[0] + Y * cam.hvec[0], X * cam.wvec[1] + Y * cam.hvec[1], X * cam.wvec[2] + Y * cam.hvec[2]};
     P3 dp{Z * cam.dir[0], Z * cam.dir[1], Z * cam.dir[2]};
-    float R_1 = r_length_3(pos.x + dp.x, pos.y + dp.y, pos.z + dp.z);
-    d = P3{R_1 * (pos.x + dp.x), R_1 * (pos.y + dp.y), R_1 * (pos.z + dp.z)};
+    s = P3{pos.x + dp.x, pos.y + dp.y, pos.z + dp.z};
     p = P3{pos.x + cam.pos[0], pos.y + cam.pos[1], pos.z + cam.pos[2]};
+}
+__device__ __forceinline__ P3 ray_direction(P3 s) {
+    float R_1 = r_length_3(s.x, s.y, s.z);
+    return P3{R_1 * s.x, R_1 * s.y, R_1 * s.z};
+}
+__device__ __forceinline__ void make_ray(const Camera& cam, uint32_t width, uint32_t height, int x, int y,
+                                         P3& p, P3& d) {
+    P3 s;
+    make_ray_raw(cam, width, height, x, y, p, s);
+    d = ray_direction(s);
 }
 
 // float -> unsigned char of Source/cuda_kernels.cu:694-699, out-of-range values saturate

@@ -59,12 +59,15 @@ __device__ __forceinline__ KernargParams* kernarg_params() {
 // the test of :712.  The steps that ARE made are the reference's, from the ray's first on (the march is chaotic:
 // where a ray lands depends on every step before), so pixels and hit masks do not change by a bit.
 // The intersection is worked out in fp32 with its own rounding priced in: `mag` bounds every magnitude that
-// enters, and the nearest approach |w| of the ray to the centre / axis is off by less than e_w, its place s0 along
+// enters, and the nearest approach |w| of the ray to the centre / axis is off by less than e_w, its place along
 // the ray by less than e_s0 (5e-6 mag is 80 half-ulps of mag: the sums below are a dozen operations long, and
-// for a cylinder the division by a = sin^2 of the angle between ray and axis stretches them by 1/a and 1/sqrt(a)).
-// The volume is grown by e_w on top of the margin, and s0's error goes into the slack.
+// for a cylinder the division by sin^2 of the angle between ray and axis stretches them by 1/sin^2 and 1/sin).
+// The volume is grown by e_w on top of the margin, and the other error goes into the slack.
+// It takes the ray's direction `v` BEFORE its normalisation (make_ray_raw): the test is homogeneous in it, and a
+// tile none of whose rays can come near the volume never pays for the exactly rounded 1/|v| (a quarter of the ray
+// set-up).  Distances along the ray are in units of |v| until the last line.
 // Returns false for a ray that can be dropped.  t_end <= RM_MAX_DIST.
-__device__ __forceinline__ bool ray_window(KernargParams* kp, P3 o, P3 d, float& t_end) {
+__device__ __forceinline__ bool ray_window(KernargParams* kp, P3 o, P3 v, float& t_end) {
     t_end = RM_MAX_DIST;
     const uint32_t kind = kp->bound_kind;
     if (kind == RM_BOUND_NONE) return true;                        // wave-uniform
@@ -72,26 +75,28 @@ __device__ __forceinline__ bool ray_window(KernargParams* kp, P3 o, P3 d, float&
     const float ocx = o.x - kp->bound_c[0], ocy = o.y - kp->bound_c[1], ocz = o.z - kp->bound_c[2];
     // ray origins far out get no window (false for NaN as well)
     bool usable = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= RM_WINDOW_MAX_COORD;
-    float px = ocx, py = ocy, pz = ocz, qx = d.x, qy = d.y, qz = d.z;       // origin and direction, across the axis for a cylinder
-    float rs = 1.f;                                                // 1 / sin of the angle between ray and axis
+    float px = ocx, py = ocy, pz = ocz, qx = v.x, qy = v.y, qz = v.z;       // origin and direction, across the axis for a cylinder
+    const float vv = v.x * v.x + v.y * v.y + v.z * v.z;
+    float a = vv;                                                  // |q|^2 = |v|^2 sin^2 of the angle between ray and axis
     if (kind == RM_BOUND_CYLINDER) {
         const float ux = kp->bound_u[0], uy = kp->bound_u[1], uz = kp->bound_u[2];
-        const float ou = ocx * ux + ocy * uy + ocz * uz, du = d.x * ux + d.y * uy + d.z * uz;
+        const float ou = ocx * ux + ocy * uy + ocz * uz, vu = v.x * ux + v.y * uy + v.z * uz;
         px -= ou * ux; py -= ou * uy; pz -= ou * uz;
-        qx -= du * ux; qy -= du * uy; qz -= du * uz;
-        const float a = qx * qx + qy * qy + qz * qz;
-        usable = usable && a >= RM_WINDOW_MIN_SIN2;
-        rs = __builtin_amdgcn_rsqf(a);                             // v_rsq_f32 is good to an ulp: inside s0's allowance below
+        qx -= vu * ux; qy -= vu * uy; qz -= vu * uz;
+        a = qx * qx + qy * qy + qz * qz;
+        usable = usable && a >= RM_WINDOW_MIN_SIN2 * vv;
     }
-    const float inv_a = rs * rs;
+    const float rs = __builtin_amdgcn_rsqf(a), inv_a = rs * rs;    // (v_rsq_f32 and v_sqrt_f32 are good to an ulp: inside the allowances below)
+    const float len = __builtin_amdgcn_sqrtf(vv), si = len * rs;   // |v|; 1 / sin (1 for a sphere)
     const float s0 = -(px * qx + py * qy + pz * qz) * inv_a;       // where the ray is nearest to the centre / axis
     const float wx = px + s0 * qx, wy = py + s0 * qy, wz = pz + s0 * qz;
     const float p2 = wx * wx + wy * wy + wz * wz;                  // and how near, squared
     const float mag = fabsf(ocx) + fabsf(ocy) + fabsf(ocz) + R;
-    const float Re = R + 5e-6f * mag * rs;
+    const float Re = R + 5e-6f * mag * si;
     const float gap = Re * Re - p2;                                // >= 0: the ray passes through the grown volume
-    // (the hardware's one-instruction square root, an ulp off at most, inside a factor that rounds it up)
-    const float leave = s0 + __builtin_amdgcn_sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f + (RM_WINDOW_SLACK + 5e-6f * mag * inv_a + 2e-6f * fabsf(s0));
+    const float s_leave = s0 + __builtin_amdgcn_sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f;
+    // in units of travelled distance: the march moves by cd * (v / |v|), rounded, and adds cd up
+    const float leave = s_leave * len + (RM_WINDOW_SLACK + 5e-6f * mag * (si * si) + 2e-6f * fabsf(s0 * len));
     if (usable && leave < RM_MAX_DIST) t_end = leave;              // (false for NaN)
     return !(usable && (gap < 0.f || leave < 0.f));
 }
@@ -255,11 +260,16 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         const uint32_t ly = tile_y * 8 + (lane >> 3);                        // row in the local buffer
         uint32_t gy = ly;                                                    // row in the image
         const uint32_t band_rows = tp->band_rows, width = tp->width, height = tp->height;
-        if (band_rows) gy = ((ly / band_rows) * tp->nranks + tp->rank) * band_rows + ly % band_rows;
+        if (band_rows) {
+            // bands are multiples of 16 rows (rm_set_bands) and a tile is 8 rows high: a tile lies in one band, and
+            // which one is the same for all its lanes - a scalar division, not one per lane
+            const uint32_t ly0 = tile_y * 8, band = ly0 / band_rows;
+            gy = (band * tp->nranks + tp->rank) * band_rows + (ly0 - band * band_rows) + (lane >> 3);
+        }
         const bool in_image = px < width && gy < height && ly < tp->local_rows;
 
-        P3 pos, rd;
-        make_ray(cam, width, height, (int)px, (int)gy, pos, rd);
+        P3 pos, rd;                                      // (rd: the direction before its normalisation until a lane needs it)
+        make_ray_raw(cam, width, height, (int)px, (int)gy, pos, rd);
         // The travelled distance at which a primary lane's march ends (ray_window: RM_MAX_DIST of :712 or less)
         // lives in the register that holds the lane's shadow term once it has turned to the light: a lane needs
         // one or the other, and the march loop has no vector register to spare (64 for 8 wavefronts per SIMD).
@@ -273,6 +283,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // (tools/microbench/valu_peak.hip).  m_p: lanes on their primary march (:626); m_s: lanes on
         // their shadow march (:660).  A lane in neither is done.
         unsigned long long m_p = __builtin_amdgcn_ballot_w64(in_image && may_hit), m_s = 0;
+        if (m_p) rd = ray_direction(rd);                 // :753-755, only in a tile that has a ray to march
         // The step caps (:626 I < 500, :660 J < 300) need no counter per lane either: a lane moves every
         // trip it is in a phase, every lane starts its primary march at trip 1 (so its step count is the
         // wave's trip count), and a lane that turns to the light at trip s has made J steps at trip s + J.
