@@ -4,7 +4,11 @@
 // the place of the SDL window.
 //
 //   rm_render --width W --height H [--input scene.sce] [--frames K] [--drag-x PX] [--drag-y PX] [--script events.txt]
-//             [--out frame.ppm] [--device D]
+//             [--out frame.ppm] [--device D] [--gpus N] [--devices D0,D1,...]
+//
+// --gpus N: the frame is dealt to N GPUs in 16-row bands (hip::raymarching over several devices, rays.hpp; D,
+// D+1, ... unless --devices names them, and a device named twice gets two contexts); every frame is rendered by
+// all of them and the PPM is the frame put together from their rows.
 //
 // --script: the reference's event loop (Source/main.cpp:144-270) driven from a file, one event per line:
 //   frame | left | right | space | pause | resume | wheel N | pan DX DY | drag DX DY
@@ -51,8 +55,8 @@ static int write_ppm(const string& path, const vector<unsigned char>& rgba, size
 int main(int argc, char** argv) {
     size_t Width = 0, Height = 0, Frames = 1;
     int DragX = 0, DragY = 0;          // scripted right-button drag per frame, pixels (Source/main.cpp:240-251)
-    int Device = 0;
-    string File, Out, Script;
+    int Device = 0, Gpus = 1;
+    string File, Out, Script, Devices;
 
     string arg;
     bitset<3> correctInit;
@@ -69,11 +73,31 @@ int main(int argc, char** argv) {
         else if (arg == "out")     { Out = argv[++I]; }
         else if (arg == "script")  { Script = argv[++I]; }
         else if (arg == "device")  { Device = atoi(argv[++I]); }
+        else if (arg == "gpus")    { Gpus = atoi(argv[++I]); }
+        else if (arg == "devices") { Devices = argv[++I]; }
     }
     if (!correctInit[0]) Width = 1920;
     if (!correctInit[1]) Height = 1080;
 
-    null::raymarching* HIP = new hip::raymarching(Device);
+    vector<int> devices;
+    if (!Devices.empty()) {
+        istringstream list(Devices);
+        for (string d; getline(list, d, ',');) {
+            char* end = nullptr;
+            long v = strtol(d.c_str(), &end, 10);
+            if (d.empty() || *end || v < 0) { cerr << "--devices: '" << d << "' is not a device number" << endl; return 1; }
+            devices.push_back(int(v));
+        }
+        if (Gpus > 1 && size_t(Gpus) != devices.size()) {
+            cerr << "--gpus " << Gpus << " but --devices names " << devices.size() << endl;
+            return 1;
+        }
+    } else {
+        if (Gpus < 1) { cerr << "--gpus " << Gpus << ": at least one" << endl; return 1; }
+        for (int g = 0; g < Gpus; ++g) devices.push_back(Device + g);
+    }
+
+    null::raymarching* HIP = new hip::raymarching(devices);
     hip::raymarching* backend = static_cast<hip::raymarching*>(HIP);
     if (int rc = HIP->Init(Width, Height)) {
         cerr << "Init failed: " << rc << " (" << rm_status_string(rc) << ")" << endl;
@@ -237,8 +261,8 @@ int main(int argc, char** argv) {
              << "ms  \t\tTask execution time : " << compute_time << "ms  " << flush;   // Source/main.cpp:287
     }
     double secs = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
-    cout << endl << Frames << " frame(s) " << Width << "x" << Height << ": " << (Width * Height * Frames / secs / 1e6)
-         << " Mrays/s wall, kernel " << (kernel_ms / Frames) << " ms/frame" << endl;
+    cout << endl << Frames << " frame(s) " << Width << "x" << Height << " on " << backend->Gpus() << " GPU context(s): "
+         << (Width * Height * Frames / secs / 1e6) << " Mrays/s wall, kernel " << (kernel_ms / Frames) << " ms/frame" << endl;
 
     if (!Out.empty()) {
         vector<unsigned char> rgba;

@@ -15,6 +15,7 @@
 // so it accepts the name and renders to its own linear RGBA8 framebuffer, which
 // ReadPixels() copies out.
 #pragma once
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -150,38 +151,81 @@ public:
 
 namespace hip {
 
+// One context per GPU.  With one device this is the reference's backend as it stands; with several, the frame is
+// dealt to them in bands of RM_FRONT_END_BAND_ROWS rows, round-robin (rm_set_bands: the split SURVEY.md 8e asks
+// for; the reference itself is single-device, Source/cuda_rays.cu:20-21).  Every GPU renders its own rows of
+// every frame from the same scene and camera block, nothing is exchanged between them, and ReadPixels() puts
+// the bands back in frame order on the host.  A device may be named more than once (several contexts on one
+// GPU): that is how the path is tested on a one-GPU box.
+constexpr size_t RM_FRONT_END_BAND_ROWS = 16;
+
 class raymarching : public null::raymarching {
-    rm_ctx* ctx_ = nullptr;
-    int device_ = 0;
+    std::vector<rm_ctx*> ctx_;
+    std::vector<int> devices_;
     int last_ = RM_OK;
     float last_ms_ = 0.f;
 
+    int each(int (*call)(rm_ctx*)) {
+        for (rm_ctx* c : ctx_)
+            if ((last_ = call(c)) != RM_OK) return last_;
+        return last_ = RM_OK;
+    }
+    void release() {
+        for (rm_ctx* c : ctx_) if (c) rm_destroy(c);
+        ctx_.clear();
+    }
+
 public:
-    explicit raymarching(int device = 0) : device_(device) {}
-    ~raymarching() override { if (ctx_) rm_destroy(ctx_); }
+    explicit raymarching(int device = 0) : devices_{ device } {}
+    explicit raymarching(const std::vector<int>& devices) : devices_(devices.empty() ? std::vector<int>{ 0 } : devices) {}
+    ~raymarching() override { release(); }
 
     int Init(const size_t& width, const size_t& height) override {
         Width = width; Height = height;
-        if (ctx_) { rm_destroy(ctx_); ctx_ = nullptr; }
-        return last_ = rm_create(device_, width, height, &ctx_);
+        release();
+        const int n = static_cast<int>(devices_.size());
+        for (int rank = 0; rank < n; ++rank) {
+            rm_ctx* c = nullptr;
+            if ((last_ = rm_create(devices_[rank], width, height, &c)) != RM_OK) { release(); return last_; }
+            ctx_.push_back(c);
+            if (n > 1 && (last_ = rm_set_bands(c, RM_FRONT_END_BAND_ROWS, rank, n)) != RM_OK) { release(); return last_; }
+        }
+        return last_ = RM_OK;
     }
-    // whole milliseconds like the reference; ProcessTime() has the float
+    // whole milliseconds like the reference; ProcessTime() has the float.  Several GPUs: all are started
+    // before any is waited for, and the time is the host's, from the first launch to the last GPU's end.
     int Process() override {
-        last_ = rm_process(ctx_, &last_ms_);
+        if (ctx_.empty()) { last_ = RM_ERR_NOT_READY; return 0; }
+        if (ctx_.size() == 1) last_ = rm_process(ctx_[0], &last_ms_);
+        else {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (each(rm_process_async) != RM_OK) return 0;
+            if (each(rm_synchronize) != RM_OK) return 0;
+            last_ms_ = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
         return last_ == RM_OK ? static_cast<int>(static_cast<uint32_t>(last_ms_)) : 0;
     }
     int Quit() override {
-        int rc = ctx_ ? rm_destroy(ctx_) : RM_OK;
-        ctx_ = nullptr;
+        int rc = RM_OK;
+        for (rm_ctx*& c : ctx_) { int r = c ? rm_destroy(c) : RM_OK; c = nullptr; if (rc == RM_OK) rc = r; }
+        ctx_.clear();
         return last_ = rc;
     }
-    int SetInfo(const rays_info& info) override { return last_ = rm_set_info(ctx_, &info); }   // SetRays is fused
-    int SetTexture(unsigned int) override { return last_ = rm_set_output(ctx_, nullptr, 0); }
+    int SetInfo(const rays_info& info) override {                     // SetRays is fused
+        for (rm_ctx* c : ctx_) if ((last_ = rm_set_info(c, &info)) != RM_OK) return last_;
+        return last_ = ctx_.empty() ? RM_ERR_NOT_READY : RM_OK;
+    }
+    int SetTexture(unsigned int) override {
+        for (rm_ctx* c : ctx_) if ((last_ = rm_set_output(c, nullptr, 0)) != RM_OK) return last_;
+        return last_ = RM_OK;
+    }
     int UnsetTexture() override { return last_ = RM_OK; }
     int SetPrimitives() override {
         PrimitivesNum = Primitives_h.size();
-        return last_ = rm_set_primitives(ctx_, Primitives_h.data(), PrimitivesNum,
-                                         sizeof(counter) == 8 ? RM_BAZO_LP64 : RM_BAZO_LLP64);
+        for (rm_ctx* c : ctx_)
+            if ((last_ = rm_set_primitives(c, Primitives_h.data(), PrimitivesNum,
+                                           sizeof(counter) == 8 ? RM_BAZO_LP64 : RM_BAZO_LLP64)) != RM_OK) return last_;
+        return last_ = ctx_.empty() ? RM_ERR_NOT_READY : RM_OK;
     }
     int SetRays() override { return last_ = RM_OK; }   // rays are derived inside Process()
 
@@ -193,15 +237,35 @@ public:
         if ((last_ = rm_load_sce(sce_path, nodes.data(), n, &n)) != RM_OK) return last_;
         SceneName = sce_path;
         PrimitivesNum = n;
-        return last_ = rm_set_nodes(ctx_, nodes.data(), n);
+        for (rm_ctx* c : ctx_) if ((last_ = rm_set_nodes(c, nodes.data(), n)) != RM_OK) return last_;
+        return last_ = ctx_.empty() ? RM_ERR_NOT_READY : RM_OK;
     }
     int ReadPixels(std::vector<unsigned char>& rgba) {
         rgba.resize(Width * Height * 4);
-        return last_ = rm_read_pixels(ctx_, rgba.data(), Width * 4);
+        if (ctx_.empty()) return last_ = RM_ERR_NOT_READY;
+        if (ctx_.size() == 1) return last_ = rm_read_pixels(ctx_[0], rgba.data(), Width * 4);
+        const size_t n = ctx_.size(), row = Width * 4;
+        std::vector<unsigned char> part;
+        for (size_t rank = 0; rank < n; ++rank) {
+            size_t rows = 0;
+            if ((last_ = rm_local_rows(ctx_[rank], &rows)) != RM_OK) return last_;
+            part.resize(rows * row);
+            if (rows && (last_ = rm_read_pixels(ctx_[rank], part.data(), row)) != RM_OK) return last_;
+            // the rank's rows are its bands one after the other (include/raymarching_amd.h, rm_set_bands)
+            size_t local = 0;
+            for (size_t band = rank, y = rank * RM_FRONT_END_BAND_ROWS; y < Height; band += n, y += n * RM_FRONT_END_BAND_ROWS) {
+                const size_t take = Height - y < RM_FRONT_END_BAND_ROWS ? Height - y : RM_FRONT_END_BAND_ROWS;
+                std::memcpy(rgba.data() + y * row, part.data() + local * row, take * row);
+                local += take;
+            }
+            if (local != rows) return last_ = RM_ERR_INVALID_ARG;
+        }
+        return last_ = RM_OK;
     }
     float ProcessTime() const { return last_ms_; }
     int LastStatus() const { return last_; }
-    rm_ctx* Context() { return ctx_; }
+    size_t Gpus() const { return ctx_.size(); }
+    rm_ctx* Context(size_t rank = 0) { return rank < ctx_.size() ? ctx_[rank] : nullptr; }
 };
 
 }  // namespace hip

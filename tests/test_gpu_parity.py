@@ -731,6 +731,28 @@ def test_front_end_ppm_matches_reference_hash(name, golden_dir, tmp_path):
         assert hashlib.sha256(f.read()).hexdigest() == GOLDEN_PPM[name]
 
 
+@pytest.mark.parametrize("gpus,height", [(2, 480), (3, 250), (8, 1080)])
+def test_front_end_several_gpu_contexts(gpus, height, stock_scenes, golden_dir, tmp_path):
+    """rm_render --gpus N: the frame dealt in 16-row bands to N contexts (here all on this GPU, --devices 0,0,...:
+    the box has one), three frames along config 5's camera path, put together on the host.  The PPM must be the
+    one-context front end's, which is the oracle's frame; 250 rows leave a last band of 10 and ranks of unequal
+    height, 1080 rows give rank 0 one band more than the others."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracing_amd", "rm_render")
+    sweep = np.fromfile(os.path.join(golden_dir, "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
+    w, frames = 320, 3
+    out = str(tmp_path / "bands.ppm")
+    run = subprocess.run([exe, "--width", str(w), "--height", str(height), "--input", os.path.join(golden_dir, "scenes", "chair.sce"),
+                          "--frames", str(frames), "--drag-x", "1", "--gpus", str(gpus), "--devices", ",".join(["0"] * gpus), "--out", out],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr + run.stdout
+    assert "on %d GPU context(s)" % gpus in run.stdout
+    ref = O.render(stock_scenes["chair"], w, height, sweep[frames - 1:frames], threads=min(16, os.cpu_count() or 4))
+    assert ref["hit"].sum() > 1000
+    with open(out, "rb") as f:
+        assert f.read() == O.ppm_bytes(ref["rgba"])
+
+
 def test_front_end_scripted_sweep(stock_scenes, golden_dir, tmp_path):
     """--frames K --drag-x 1 is config 5's camera path: the front end's own float
     maths (Source/main.cpp:240-266) must land on the committed rays_info of frame K-1, so the PPM of

@@ -251,6 +251,16 @@ def test_cpp_front_end_is_built():
     assert os.path.exists(os.path.join(ROOT, "raytracing_amd", "rm_render")), "run __graft_entry__.build()"
 
 
+def test_cpp_front_end_checks_its_device_list():
+    """--gpus / --devices are checked before anything touches a GPU."""
+    import subprocess
+    exe = os.path.join(ROOT, "raytracing_amd", "rm_render")
+    for args, text in [(["--gpus", "2", "--devices", "0"], "--devices names 1"), (["--devices", "0,x"], "not a device number"),
+                       (["--gpus", "0"], "at least one")]:
+        run = subprocess.run([exe, "--width", "64", "--height", "48"] + args, capture_output=True, text=True, timeout=60)
+        assert run.returncode == 1 and text in run.stderr, (args, run.stderr)
+
+
 @pytest.mark.parametrize("name", ["chair", "infinity", "carved", "deep_values", "portanta_nested", "csg1024"])
 def test_generated_code_compiles_for_gfx950_without_a_device(name, stock_scenes):
     """rm_jit_check: the per-scene HIP source every generator writes (fused distance/normal pair, the
