@@ -216,20 +216,22 @@ def main():
         streams.append(st)
 
     band = 0
-    # Frames per launch (rm_set_batch): up to 16 at every N, and a timed run of K frames goes out in the fewest
+    # Frames per launch (rm_set_batch): up to 32 (RM_MAX_BATCH), and a timed run of K frames goes out in the fewest
     # launches of nearly equal size (FrameBatcher.plan).  The reference renders a frame per Process() call;
     # here the tiles of consecutive frames of the sequence form one pool for the persistent wavefronts, so the few
     # long tiles of a frame (one ray marching ~500 steps is 0.2 ms however idle the chip is) run beside the short
     # tiles of the others.  At N>1 it is what makes a rank's launch worth launching: an 8-rank share of ONE frame
     # is too little work to fill the chip for as long as its longest ray marches.  `single_frame_launch` in the
     # output is the frame-at-a-time figure (the reference's own call pattern).
-    # N>1: up to 32, so that a rank's launch at N=8 holds four frames' worth of tiles (tools/slice_rate.py, render
+    # N=1, chair 4K, same box: 0.1519 ms per frame in launches of 16, 0.1506 of 20, 0.1500 of 29; the driver's 20 steps
+    # are one launch (0.152; as two of 10: 0.154-0.155).
+    # N>1: a rank's launch at N=8 then holds four frames' worth of tiles (tools/slice_rate.py, render
     # side only, 3 contexts in flight: 48 k shares/s per GPU at 4K against 6.4 k whole frames/s on one GPU, 11.1 k
     # against 1.43 k at 8K), and at least two launches, so that a gather runs under the next launch's kernel.
-    batch = args.frames_per_launch or (16 if not multi else 32)
+    batch = args.frames_per_launch or 32
     batch = max(1, min(32, batch))
-    # the timed run's launch size is the warm-up's too (20 steps at up to 16 per launch: 10 and 10, and the
-    # warm-up's launches hold 10): a launch learns its tile order and its grid from the launch before it
+    # the timed run's launch size is the warm-up's too (70 steps at up to 32 per launch: 24, 23 and 23, and the
+    # warm-up's launches hold 24): a launch learns its tile order and its grid from the launch before it
     if args.steps > 0:
         n_launches = max(-(-args.steps // batch), min(2, args.steps) if multi else 1)
         batch = -(-args.steps // n_launches)
