@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the extra frame-per-launch measurement (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=0, help="contexts taking launches in turn (0 = 1 for N=1, 3 for N>1)")
+    ap.add_argument("--rank0-share", type=float, default=None,
+                    help="N>1: rank 0's bands as a fraction of another rank's (it also rebuilds the frames); default: measured")
     ap.add_argument("--frames-per-launch", type=int, default=0,
                     help="most frames whose tiles one launch pools (rm_set_batch), 1..32; 0 = 16 on one GPU, 32 on several")
     ap.add_argument("--warmup-seconds", type=float, default=0.25,
@@ -235,60 +237,83 @@ def main():
     if args.steps > 0:
         n_launches = max(-(-args.steps // batch), min(2, args.steps) if multi else 1)
         batch = -(-args.steps // n_launches)
+    weights, deal_note = None, None
     if multi:
         # Every rank renders its bands of a frame; what travels to rank 0 is the frame's luminance plane
         # (1 B/px: a pixel is a function of that byte, include/raymarching_amd.h), the frames of a launch
-        # in one RCCL gather, and rank 0 rebuilds each RGBA8 frame from the planes of all ranks
-        # (rm_assemble_luminance).  At 4 B/px and 8 ranks the gather alone (29 MB per frame into one
-        # GPU's xGMI links) would bound the frame rate below what the kernels deliver.
+        # in one RCCL gather, and rank 0 rebuilds the RGBA8 frames of the launch from the planes of all ranks in
+        # one kernel (rm_assemble_luminance_batch).  At 4 B/px and 8 ranks the gather alone (29 MB per frame into
+        # one GPU's xGMI links) would bound the frame rate below what the kernels deliver.
         band = args.band_rows or tiling.default_band_rows(h, world)
-        rows_max = tiling.bands_per_rank(h, band, world) * band
+        # Rank 0 also writes every frame's 4 B/px (5 B/px of HBM traffic a frame: 9 us at 4K and 38 us at 8K alone on
+        # the chip, more beside its own render kernels - an even share of the rendering is 20 and 45 us), so it is
+        # dealt fewer bands (rm_set_band_pattern).  How many fewer is measured below, before the warm-up
+        # (--rank0-share overrides it: 1 = an even deal).
         comm_stream = torch.cuda.Stream(device=dev)
-        bufs, parts, rendered, gathered = [], [], [], []
-        for rm in ctxs:
-            rm.set_bands(band, rank, world)
-            bufs.append(torch.zeros((batch, rows_max, w), dtype=torch.uint8, device=dev))
-            rm.set_luminance_output(bufs[-1].data_ptr(), w)
-            parts.append(torch.zeros((world, batch, rows_max, w), dtype=torch.uint8, device=dev) if rank == 0 else None)
-            rendered.append(torch.cuda.Event())
-            gathered.append(torch.cuda.Event())
-        frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+        rendered = [torch.cuda.Event() for _ in ctxs]
+        gathered = [torch.cuda.Event() for _ in ctxs]
+        # the frames of the launch gathered last, rebuilt (gathers and rebuilds run in order on one stream)
+        frames_out = torch.zeros((batch, h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+        frame = None
         frames = None
-        strides = (0, rows_max * w)                    # RGBA8 into the context's own planes, luminance into the slab
+        lay = {}
+
+        def lay_out(owner):
+            """Bands dealt as `owner` says; slabs and parts sized for that deal (what the gather moves)."""
+            rows = -(-tiling.max_local_rows(h, band, world, owner) // 16) * 16
+            lay["rows_max"], lay["bufs"], lay["parts"] = rows, [], []
+            for rm in ctxs:
+                rm.set_bands(band, rank, world, owner)
+                lay["bufs"].append(torch.zeros((batch, rows, w), dtype=torch.uint8, device=dev))
+                rm.set_luminance_output(lay["bufs"][-1].data_ptr(), w)
+                lay["parts"].append(torch.zeros((world, batch, rows, w), dtype=torch.uint8, device=dev) if rank == 0 else None)
+                rm.set_batch(batch, 0, rows * w)       # RGBA8 into the context's own planes, luminance into the slab
+
+        def rebuild(j, n):
+            rows = lay["rows_max"]
+            ctxs[j].assemble_luminance_batch(lay["parts"][j].data_ptr(), batch * rows * w, rows * w, w, n,
+                                             frames_out.data_ptr(), w * 4, h * w * 4, stream=comm_stream.cuda_stream)
+
+        weights = tiling.lighter_rank0(world, 1.0 if args.rank0_share is None else args.rank0_share)
+        lay_out(tiling.deal(weights))
+        lay["gather"] = True
     else:
         frames = [torch.zeros((batch, h, w, 4), dtype=torch.uint8, device=dev) for _ in ctxs]
         for rm, f in zip(ctxs, frames):
             rm.set_output(f.data_ptr(), w * 4)
         frame = None                                   # the last frame rendered: set by launch()
-        strides = (h * w * 4, 0)
-    for rm in ctxs:                                    # room for `batch` frames per launch, once, before anything is timed
-        rm.set_batch(batch, *strides)
+        for rm in ctxs:                                # room for `batch` frames per launch, once, before anything is timed
+            rm.set_batch(batch, h * w * 4, 0)
     def before_launch(j):
         if multi:
             streams[j].wait_event(gathered[j])         # context j's slab is free again
+
+    host_times = [] if os.environ.get("RM_BENCH_HOST_TIMES") else None     # seconds of host time per after_launch
 
     def after_launch(j, n):
         """N>1: the launch's luminance planes to rank 0 in one gather, RGBA8 frames rebuilt there."""
         if not multi:
             return
-        rm = ctxs[j]
+        t_host = time.perf_counter()
         rendered[j].record(streams[j])
         comm_stream.wait_event(rendered[j])
         with torch.cuda.stream(comm_stream):           # same order of gathers on every rank
-            if rehearsal:
+            if not lay["gather"]:
+                pass                                   # the deal is being measured: render and rebuild only
+            elif rehearsal:
                 comm_stream.synchronize()
-                host = bufs[j][:n].cpu()
+                host = lay["bufs"][j][:n].cpu()
                 got = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, got, dst=0)
                 if rank == 0:
-                    parts[j][:, :n].copy_(torch.stack(got))
+                    lay["parts"][j][:, :n].copy_(torch.stack(got))
             else:
-                dist.gather(bufs[j][:n], list(parts[j][:, :n].unbind(0)) if rank == 0 else None, dst=0)     # the n frames of this launch only
+                dist.gather(lay["bufs"][j][:n], list(lay["parts"][j][:, :n].unbind(0)) if rank == 0 else None, dst=0)     # the n frames of this launch only
             if rank == 0:
-                for slot in range(n):
-                    rm.assemble_luminance(parts[j].data_ptr() + slot * rows_max * w, batch * rows_max * w, w,
-                                          frame.data_ptr(), w * 4, stream=comm_stream.cuda_stream)
+                rebuild(j, n)
             gathered[j].record(comm_stream)
+        if host_times is not None:
+            host_times.append(time.perf_counter() - t_host)
 
     from raytracing_amd.batching import FrameBatcher
     run = FrameBatcher(ctxs, batch, before=before_launch, after=after_launch)
@@ -303,6 +328,38 @@ def main():
         if multi:
             comm_stream.synchronize()
         torch.cuda.synchronize()
+
+    if multi and world > 1 and args.rank0_share is None:
+        # The deal.  For each candidate share of rank 0 every rank runs its part of the job without the collective
+        # - its bands rendered in launches on its contexts in turn, rank 0 rebuilding every launch's frames beside
+        # them - and reports frames per second; the job runs at its slowest rank's rate, and the candidate where
+        # that is highest is taken.  (Measured rather than modelled: the rebuild costs rank 0 more than it takes
+        # alone, its workgroups wait for slots the persistent render wavefronts hold; one GPU, tools/slice_rate.py,
+        # 8 ranks at 4K: even deal 33 k frames/s on rank 0 against 45 k on the others, a quarter share 55 k
+        # against 44 k.)
+        shares = (1.0, 0.75, 0.5, 0.375, 0.25, 0.125)
+        lay["gather"] = False
+        table = []
+        for share in shares:
+            lay_out(tiling.deal(tiling.lighter_rank0(world, share)))
+            for k in range(2 * batch * in_flight):     # the tile order and the grid are learnt from the launch before
+                step(k)
+            drain()
+            t_deal, done = time.perf_counter(), 0
+            while done < 3 * batch * in_flight or time.perf_counter() - t_deal < 0.04:     # no collective: ranks need not agree
+                for k in range(batch * in_flight):
+                    step(k)
+                done += batch * in_flight
+            drain()
+            table.append(done / (time.perf_counter() - t_deal))
+        lay["gather"] = True
+        rates = torch.tensor(table, dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(rates, op=dist.ReduceOp.MIN)
+        rates = [float(x) for x in rates.cpu()]
+        best = max(range(len(shares)), key=lambda k: rates[k])
+        weights = tiling.lighter_rank0(world, shares[best])
+        lay_out(tiling.deal(weights))
+        deal_note = {"rank0_share_tried": list(shares), "slowest_rank_frames_per_s_without_gather": rates}
 
     # Warm-up: at least --warmup frames, in whole launches, and at least --warmup-seconds of them: a fresh
     # box needs a few hundred milliseconds of work before its clocks are where a long run has them, and the
@@ -344,11 +401,16 @@ def main():
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
     launches = max(1, run.launches)
+    if host_times:
+        print("host time per after_launch (gather + rebuild), last %d: median %.1f us" % (
+            launches, 1e6 * sorted(host_times[-launches:])[launches // 2]), file=sys.stderr)
     # One context: the kernel's average duration (launch to launch on its stream).  With several
     # in flight kernels overlap; the region's time per launch is what counts then.
     kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / launches
     if not multi:
         frame = frames[run.last[0]][run.last[1]]
+    elif rank == 0:
+        frame = frames_out[run.last[1]]
 
     if multi:
         tmax = torch.tensor([secs], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -372,8 +434,10 @@ def main():
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
                        "scene_nodes": int(len(nodes)), "contexts_in_flight": in_flight, "frames_per_launch": args.steps / launches, "frames_per_launch_max": batch,
                        "partition": "whole frame" if not multi else
-                       "row bands of %d dealt round-robin over %d ranks; the %d frames of a launch gathered together to rank 0 "
-                       "as luminance planes (1 B/px, RCCL), RGBA8 frames rebuilt there" % (band, world, batch)},
+                       "row bands of %d dealt to %d ranks %s; the %d frames of a launch gathered together to rank 0 "
+                       "as luminance planes (1 B/px, RCCL), RGBA8 frames rebuilt there in one kernel" % (
+                           band, world, "evenly" if len(set(weights)) == 1 else "by weight (rank 0 also rebuilds the frames)", batch),
+                       **({"band_weights": weights} if multi else {}), **({"band_deal_measured": deal_note} if deal_note else {})},
             "parity": {"hit_pixels": hits, "rgba_sha256": sha,
                        "golden_hit_pixels": want["hits"] if want else None,
                        "frame_matches_golden": (sha == want["rgba_sha256"]) if want else None},

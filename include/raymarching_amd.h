@@ -123,8 +123,15 @@ int rm_set_info_batch(rm_ctx* ctx, const rm_rays_info* infos, size_t n);
  * Source/cuda_rays.cu:20-21).  The image is cut into bands of `band_rows` rows
  * (a multiple of 16); this context renders bands b with b % nranks == rank,
  * packed top to bottom into its output buffer.  rm_local_rows reports how many
- * rows that is.  band_rows = 0 restores whole-frame rendering. */
+ * rows that is.  band_rows = 0 restores whole-frame rendering.
+ * rm_set_band_pattern deals the bands unevenly: owner[k] (k < period <=
+ * RM_MAX_BAND_PERIOD) is the rank that renders bands b with b % period == k, so a
+ * rank that has other work - rank 0 receives every rank's rows and rebuilds the
+ * frames - can be given fewer bands than the others (none at all is allowed; at
+ * most 16 of a period).  rm_set_bands(ctx, rows, rank, nranks) is the pattern
+ * owner[k] = k of period nranks (nranks <= RM_MAX_BAND_PERIOD). */
 int rm_set_bands(rm_ctx* ctx, size_t band_rows, int rank, int nranks);
+int rm_set_band_pattern(rm_ctx* ctx, size_t band_rows, const unsigned char* owner, size_t period, int rank, int nranks);
 int rm_local_rows(rm_ctx* ctx, size_t* rows);
 
 /* Optional luminance plane (no counterpart in the reference): besides the RGBA8
@@ -138,12 +145,22 @@ int rm_local_rows(rm_ctx* ctx, size_t* rows);
 int rm_set_luminance_output(rm_ctx* ctx, void* device_l8, size_t pitch_bytes);
 
 /* Rebuilds the whole RGBA8 frame from the luminance planes of all ranks: part r
- * (rank r's plane, rows packed as rm_set_bands lays them out, `part_pitch_bytes`
- * apart) starts at device_parts + r * rank_stride_bytes.  Uses this context's
- * image size and band layout (band_rows = 0: one part, a plain expansion).
- * Runs on `hip_stream` (a hipStream_t; NULL = the null stream), asynchronously. */
+ * (rank r's plane, rows packed as rm_set_bands / rm_set_band_pattern lay them
+ * out, `part_pitch_bytes` apart) starts at device_parts + r * rank_stride_bytes.
+ * Uses this context's image size and band layout (band_rows = 0: one part, a
+ * plain expansion).  Runs on `hip_stream` (a hipStream_t; NULL = the null
+ * stream), asynchronously.
+ * rm_assemble_luminance_batch rebuilds the `frames` frames of a launch in one
+ * kernel: frame f's plane of rank r starts part_frame_stride_bytes * f into
+ * part r, and its RGBA8 frame rgba_frame_stride_bytes * f into device_rgba (the
+ * frames must not overlap).  Rows that allow it (pitches, strides and bases
+ * that are multiples of 4 bytes on the luminance side and of 16 on the RGBA8
+ * side) are moved as 4-byte loads and 16-byte stores. */
 int rm_assemble_luminance(rm_ctx* ctx, const void* device_parts, size_t rank_stride_bytes, size_t part_pitch_bytes,
                           void* device_rgba, size_t pitch_bytes, void* hip_stream);
+int rm_assemble_luminance_batch(rm_ctx* ctx, const void* device_parts, size_t rank_stride_bytes, size_t part_frame_stride_bytes,
+                                size_t part_pitch_bytes, size_t frames, void* device_rgba, size_t pitch_bytes,
+                                size_t rgba_frame_stride_bytes, void* hip_stream);
 
 /* Optional explicit hit mask: one byte per
  * pixel, 1 where the pixel was shaded.  enable != 0 allocates it, zeroed. */

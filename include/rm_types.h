@@ -145,6 +145,10 @@ typedef struct rm_scene_bound {
 #define RM_WINDOW_MAX_COORD  16384.f    /* rays starting farther out, and volumes centred or reaching farther out, get no window */
 #define RM_WINDOW_MIN_SIN2   .01f       /* rays within 5.7 degrees of a cylinder's axis get no window */
 
+/* Multi-GPU row bands (rm_set_band_pattern): bands are dealt to ranks in runs of at most this many bands, to at
+ * most this many ranks */
+#define RM_MAX_BAND_PERIOD   64
+
 #ifdef __cplusplus
 }
 #endif

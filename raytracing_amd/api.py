@@ -24,12 +24,12 @@ BAZO_LP64, BAZO_LLP64, BAZO_SCE = 0, 1, 2
 # every symbol include/raymarching_amd.h declares
 EXPORTS = [
     "rm_decode_bazo", "rm_load_sce", "rm_save_sce", "rm_create", "rm_destroy", "rm_set_stream",
-    "rm_set_output", "rm_set_primitives", "rm_set_nodes", "rm_set_info", "rm_set_bands",
+    "rm_set_output", "rm_set_primitives", "rm_set_nodes", "rm_set_info", "rm_set_bands", "rm_set_band_pattern",
     "rm_local_rows", "rm_enable_hit_mask", "rm_process", "rm_process_async", "rm_synchronize",
     "rm_read_pixels", "rm_read_hit_mask", "rm_device_framebuffer", "rm_get_scene_stats",
     "rm_flatten_scene", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
-    "rm_set_luminance_output", "rm_assemble_luminance", "rm_set_batch", "rm_set_info_batch",
+    "rm_set_luminance_output", "rm_assemble_luminance", "rm_assemble_luminance_batch", "rm_set_batch", "rm_set_info_batch",
     "rm_process_static", "rm_debug_set_watchdog", "rm_scene_bound_of", "rm_set_ray_windows",
 ]
 
@@ -92,10 +92,12 @@ def lib():
             "rm_set_batch": [vp, sz, sz, sz],
             "rm_set_info_batch": [vp, vp, sz],
             "rm_assemble_luminance": [vp, vp, sz, sz, vp, sz, vp],
+            "rm_assemble_luminance_batch": [vp, vp, sz, sz, sz, sz, vp, sz, sz, vp],
             "rm_set_primitives": [vp, vp, sz, i32],
             "rm_set_nodes": [vp, vp, sz],
             "rm_set_info": [vp, vp],
             "rm_set_bands": [vp, sz, i32, i32],
+            "rm_set_band_pattern": [vp, sz, vp, sz, i32, i32],
             "rm_local_rows": [vp, C.POINTER(sz)],
             "rm_enable_hit_mask": [vp, i32],
             "rm_process": [vp, C.POINTER(C.c_float)],
@@ -256,8 +258,21 @@ class Raymarching:
         _check(lib().rm_assemble_luminance(self._ctx, C.c_void_p(parts_ptr), rank_stride, part_pitch, C.c_void_p(rgba_ptr),
                                            pitch_bytes, C.c_void_p(stream or None)), "rm_assemble_luminance")
 
-    def set_bands(self, band_rows, rank, nranks):
-        _check(lib().rm_set_bands(self._ctx, band_rows, rank, nranks), "rm_set_bands")
+    def set_bands(self, band_rows, rank, nranks, owner=None):
+        """owner: the rank of every band of a run (rm_set_band_pattern); None: band b to rank b % nranks."""
+        if owner is None:
+            _check(lib().rm_set_bands(self._ctx, band_rows, rank, nranks), "rm_set_bands")
+        else:
+            table = (C.c_ubyte * len(owner))(*owner)
+            _check(lib().rm_set_band_pattern(self._ctx, band_rows, table, len(owner), rank, nranks), "rm_set_band_pattern")
+
+    def assemble_luminance_batch(self, parts_ptr, rank_stride, part_frame_stride, part_pitch, frames, rgba_ptr, pitch_bytes,
+                                 rgba_frame_stride, stream=None):
+        """The frames of a launch rebuilt in one kernel (frame f: part_frame_stride * f into every part,
+        rgba_frame_stride * f into the output)."""
+        _check(lib().rm_assemble_luminance_batch(self._ctx, C.c_void_p(parts_ptr), rank_stride, part_frame_stride, part_pitch, frames,
+                                                 C.c_void_p(rgba_ptr), pitch_bytes, rgba_frame_stride, C.c_void_p(stream or None)),
+               "rm_assemble_luminance_batch")
 
     def local_rows(self):
         n = C.c_size_t(0)

@@ -4,6 +4,7 @@
 // device every call that would render fails with the HIP error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -45,7 +46,10 @@ struct rm_ctx {
     size_t out_frame_stride = 0, lum_frame_stride = 0;   // 0: planes packed (pitch x local rows)
     size_t fb_bytes = 0, hit_bytes = 0;
 
+    // row bands (rm_set_band_pattern): owner[k] renders the bands b with b % period == k
     size_t band_rows = 0; int rank = 0, nranks = 1;
+    size_t band_period = 1;
+    uint8_t band_owner[RM_MAX_BAND_PERIOD] = {0};
     size_t local_rows = 0;
     uint32_t evaluator = 0;
     size_t lds_bytes = 0;
@@ -119,12 +123,12 @@ void list_caps(size_t tiles, uint32_t* list_cap, uint32_t* overflow_cap) {
     *list_cap = static_cast<uint32_t>(tiles / 4 + 16);
 }
 
-size_t count_local_rows(size_t height, size_t band_rows, int rank, int nranks) {
-    if (!band_rows) return height;
+size_t count_local_rows(const rm_ctx* c, int rank) {
+    if (!c->band_rows) return c->height;
     size_t rows = 0;
-    for (size_t b = 0, y = 0; y < height; ++b, y += band_rows)
-        if (static_cast<int>(b % static_cast<size_t>(nranks)) == rank)
-            rows += (height - y < band_rows) ? height - y : band_rows;
+    for (size_t b = 0, y = 0; y < c->height; ++b, y += c->band_rows)
+        if (c->band_owner[b % c->band_period] == rank)
+            rows += (c->height - y < c->band_rows) ? c->height - y : c->band_rows;
     return rows;
 }
 
@@ -153,8 +157,12 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     p.height = static_cast<uint32_t>(c->height);
     p.local_rows = static_cast<uint32_t>(c->local_rows);
     p.band_rows = static_cast<uint32_t>(c->band_rows);
-    p.rank = static_cast<uint32_t>(c->rank);
-    p.nranks = static_cast<uint32_t>(c->nranks);
+    p.band_period = static_cast<uint32_t>(c->band_period);
+    p.band_own = 0;
+    for (uint32_t k = 0; k < RM_MAX_BAND_OWN; ++k) p.band_slot[k] = 0;
+    if (c->band_rows)
+        for (size_t k = 0; k < c->band_period; ++k)
+            if (c->band_owner[k] == c->rank && p.band_own < RM_MAX_BAND_OWN) p.band_slot[p.band_own++] = static_cast<uint32_t>(k);
     p.evaluator = c->evaluator;
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;
@@ -544,22 +552,44 @@ int rm_set_luminance_output(rm_ctx* c, void* device_l8, size_t pitch_bytes) {
     return RM_OK;
 }
 
-int rm_assemble_luminance(rm_ctx* c, const void* device_parts, size_t rank_stride_bytes, size_t part_pitch_bytes,
-                          void* device_rgba, size_t pitch_bytes, void* hip_stream) {
-    if (!c || !device_parts || !device_rgba) return RM_ERR_INVALID_ARG;
-    if (part_pitch_bytes < c->width || pitch_bytes < c->width * 4 || (pitch_bytes & 3) ||
+int rm_assemble_luminance_batch(rm_ctx* c, const void* device_parts, size_t rank_stride_bytes, size_t part_frame_stride_bytes,
+                                size_t part_pitch_bytes, size_t frames, void* device_rgba, size_t pitch_bytes,
+                                size_t rgba_frame_stride_bytes, void* hip_stream) {
+    if (!c || !device_parts || !device_rgba || frames == 0 || frames > RM_MAX_BATCH) return RM_ERR_INVALID_ARG;
+    if (part_pitch_bytes < c->width || pitch_bytes < c->width * 4 || (pitch_bytes & 3) || (rgba_frame_stride_bytes & 3) ||
         (reinterpret_cast<uintptr_t>(device_rgba) & 3))
         return RM_ERR_INVALID_ARG;
-    // every rank's part must hold that rank's rows: the largest share is rank 0's
-    const size_t nranks = c->band_rows ? static_cast<size_t>(c->nranks) : 1;
-    const size_t rows_max = c->band_rows ? count_local_rows(c->height, c->band_rows, 0, c->nranks) : c->height;
-    if (nranks > 1 && rank_stride_bytes < rows_max * part_pitch_bytes) return RM_ERR_INVALID_ARG;
+    rm::AssembleParams p{};
+    size_t rows_max = c->height;
+    if (c->band_rows) {
+        // every rank's part must hold that rank's rows, every frame's plane the largest share
+        rows_max = 0;
+        for (size_t k = 0; k < c->band_period; ++k) {
+            const uint8_t r = c->band_owner[k];
+            p.owner[k] = r;
+            p.index[k] = p.own[r]++;
+        }
+        for (int r = 0; r < c->nranks; ++r) rows_max = std::max(rows_max, count_local_rows(c, r));
+        if (c->nranks > 1 && rank_stride_bytes < rows_max * part_pitch_bytes) return RM_ERR_INVALID_ARG;
+    }
+    if (frames > 1 && (part_frame_stride_bytes < rows_max * part_pitch_bytes || rgba_frame_stride_bytes < c->height * pitch_bytes))
+        return RM_ERR_INVALID_ARG;
+    p.parts = static_cast<const uint8_t*>(device_parts);
+    p.rank_stride = rank_stride_bytes; p.part_frame_stride = part_frame_stride_bytes; p.part_pitch = part_pitch_bytes;
+    p.rgba = static_cast<uint8_t*>(device_rgba);
+    p.pitch = pitch_bytes; p.rgba_frame_stride = rgba_frame_stride_bytes;
+    p.width = static_cast<uint32_t>(c->width); p.height = static_cast<uint32_t>(c->height);
+    p.band_rows = static_cast<uint32_t>(c->band_rows); p.period = static_cast<uint32_t>(c->band_period);
+    p.vector = ((reinterpret_cast<uintptr_t>(device_parts) | rank_stride_bytes | part_frame_stride_bytes | part_pitch_bytes) & 3) == 0 &&
+               ((reinterpret_cast<uintptr_t>(device_rgba) | pitch_bytes | rgba_frame_stride_bytes) & 15) == 0;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(rm::launch_assemble_luminance(static_cast<const uint8_t*>(device_parts), rank_stride_bytes, part_pitch_bytes,
-                                          static_cast<uint32_t>(c->width), static_cast<uint32_t>(c->height),
-                                          static_cast<uint32_t>(c->band_rows), static_cast<uint32_t>(nranks),
-                                          static_cast<uint8_t*>(device_rgba), pitch_bytes, static_cast<hipStream_t>(hip_stream)));
+    HIP_TRY(rm::launch_assemble_luminance(p, static_cast<uint32_t>(frames), static_cast<hipStream_t>(hip_stream)));
     return RM_OK;
+}
+
+int rm_assemble_luminance(rm_ctx* c, const void* device_parts, size_t rank_stride_bytes, size_t part_pitch_bytes,
+                          void* device_rgba, size_t pitch_bytes, void* hip_stream) {
+    return rm_assemble_luminance_batch(c, device_parts, rank_stride_bytes, 0, part_pitch_bytes, 1, device_rgba, pitch_bytes, 0, hip_stream);
 }
 
 int rm_set_primitives(rm_ctx* c, const void* bazo_records, size_t n, int layout) {
@@ -644,17 +674,35 @@ int rm_set_batch(rm_ctx* c, size_t frames, size_t rgba_frame_stride_bytes, size_
     return RM_OK;
 }
 
-int rm_set_bands(rm_ctx* c, size_t band_rows, int rank, int nranks) {
+int rm_set_band_pattern(rm_ctx* c, size_t band_rows, const unsigned char* owner, size_t period, int rank, int nranks) {
     if (!c) return RM_ERR_INVALID_ARG;
-    if (band_rows != 0 && ((band_rows % 16) || nranks < 1 || rank < 0 || rank >= nranks)) return RM_ERR_INVALID_ARG;
+    if (band_rows != 0) {
+        if ((band_rows % 16) || !owner || period < 1 || period > RM_MAX_BAND_PERIOD || nranks < 1 || nranks > RM_MAX_BAND_PERIOD ||
+            rank < 0 || rank >= nranks) return RM_ERR_INVALID_ARG;
+        size_t mine = 0;
+        for (size_t k = 0; k < period; ++k) {
+            if (owner[k] >= nranks) return RM_ERR_INVALID_ARG;
+            mine += owner[k] == rank;
+        }
+        if (mine > RM_MAX_BAND_OWN) return RM_ERR_INVALID_ARG;
+    }
     HIP_TRY(hipSetDevice(c->device));
-    if (band_rows == 0) { c->band_rows = 0; c->rank = 0; c->nranks = 1; c->local_rows = c->height; }
+    if (band_rows == 0) { c->band_rows = 0; c->rank = 0; c->nranks = 1; c->band_period = 1; c->band_owner[0] = 0; c->local_rows = c->height; }
     else {
-        c->band_rows = band_rows; c->rank = rank; c->nranks = nranks;
-        c->local_rows = count_local_rows(c->height, band_rows, rank, nranks);
+        c->band_rows = band_rows; c->rank = rank; c->nranks = nranks; c->band_period = period;
+        for (size_t k = 0; k < period; ++k) c->band_owner[k] = owner[k];
+        c->local_rows = count_local_rows(c, rank);
     }
     HIP_TRY(reset_schedule(c));          // tiles are numbered over the local rows
     return RM_OK;
+}
+
+int rm_set_bands(rm_ctx* c, size_t band_rows, int rank, int nranks) {
+    if (band_rows == 0) return rm_set_band_pattern(c, 0, nullptr, 0, 0, 1);
+    if (nranks < 1 || nranks > RM_MAX_BAND_PERIOD) return RM_ERR_INVALID_ARG;
+    unsigned char owner[RM_MAX_BAND_PERIOD];
+    for (int k = 0; k < nranks; ++k) owner[k] = static_cast<unsigned char>(k);
+    return rm_set_band_pattern(c, band_rows, owner, static_cast<size_t>(nranks), rank, nranks);
 }
 
 int rm_local_rows(rm_ctx* c, size_t* rows) {

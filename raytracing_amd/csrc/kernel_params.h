@@ -69,6 +69,10 @@
 // (64 B each; the segment holds 4 KiB)
 #define RM_MAX_BATCH 32
 
+// row bands (rm_set_band_pattern): a run of bands is at most RM_MAX_BAND_PERIOD long (include/raymarching_amd.h),
+// and one context renders at most this many bands of a run
+#define RM_MAX_BAND_OWN 16
+
 namespace rm {
 
 // frames of the per-lane tree walker's private stack (>= scene_build.h kMaxTreeDepth)
@@ -89,7 +93,11 @@ struct RenderParams {
     uint32_t n_nodes;
     uint32_t width, height;       // whole image
     uint32_t local_rows;          // rows this context renders
-    uint32_t band_rows, rank, nranks;
+    // row bands: 0 = the whole frame; else of every run of band_period bands this context renders band_own, the
+    // ones at places band_slot[0..band_own) of the run, packed top to bottom (rm_set_bands: band_period = nranks,
+    // band_own = 1, band_slot[0] = rank)
+    uint32_t band_rows, band_period, band_own;
+    uint32_t band_slot[RM_MAX_BAND_OWN];
     uint32_t evaluator;           // 0 distance program, 1 tree walker
     uint32_t nframes;             // frames of this launch (rm_set_batch): tile ids run over all of them
     size_t frame_stride, hit_frame_stride, lum_frame_stride;     // bytes from a frame's plane to the next frame's
@@ -119,6 +127,18 @@ struct RenderParams {
 };
 
 #ifndef __HIPCC_RTC__
+// rm_assemble_luminance: where every image row lies in the ranks' parts, and the planes
+struct AssembleParams {
+    const uint8_t* parts;  size_t rank_stride, part_frame_stride, part_pitch;
+    uint8_t* rgba;         size_t pitch, rgba_frame_stride;
+    uint32_t width, height;
+    uint32_t band_rows, period;   // band_rows 0: one part, rows as they are
+    uint32_t vector;              // every row of every plane allows 4-byte loads and 16-byte stores
+    uint8_t owner[RM_MAX_BAND_PERIOD];   // of place k of a run of bands: the rank that renders it...
+    uint8_t index[RM_MAX_BAND_PERIOD];   // ...and which of that rank's bands of the run it is
+    uint8_t own[RM_MAX_BAND_PERIOD];     // own[r]: bands of a run that rank r renders
+};
+
 hipError_t launch_render(const RenderParams& prm, unsigned blocks, size_t lds_bytes, hipStream_t stream);
 // resident workgroups per CU of the ahead-of-time render kernel with `lds_bytes` of dynamic LDS
 hipError_t render_occupancy(size_t lds_bytes, int* blocks_per_cu);
@@ -131,9 +151,8 @@ hipError_t kernel_attributes(int* vgprs, int* scratch_bytes);
 // device address of the static scheduler block (RM_STATIC_DWORDS dwords) on `device`, which must be current
 hipError_t static_scratch_address(int device, uint32_t** ptr);
 // enumeration proofs of device_math.h's short sqrt / quotient sequences (mismatch counts in *bad)
-// luminance planes of `nranks` band-interleaved parts -> one RGBA8 frame (rm_assemble_luminance)
-hipError_t launch_assemble_luminance(const uint8_t* parts, size_t rank_stride, size_t part_pitch, uint32_t width, uint32_t height,
-                                     uint32_t band_rows, uint32_t nranks, uint8_t* rgba, size_t pitch, hipStream_t stream);
+// luminance planes of the ranks' band-interleaved parts -> RGBA8 frames (rm_assemble_luminance[_batch])
+hipError_t launch_assemble_luminance(const AssembleParams& prm, uint32_t frames, hipStream_t stream);
 hipError_t launch_verify_sqrt(uint32_t first, unsigned long long count, unsigned long long* bad, hipStream_t stream);
 hipError_t launch_verify_div(const float* c, const float* rc, uint32_t n, uint32_t first, unsigned long long count,
                              unsigned long long* bad, hipStream_t stream);

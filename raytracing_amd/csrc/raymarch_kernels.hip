@@ -134,36 +134,75 @@ verify_div_kernel(const float* __restrict__ c, const float* __restrict__ rc, uin
 
 // ---- launchers (called from capi.cpp) -----------------------------------------
 
-// One thread per 4 pixels of the assembled frame: finds the rank and packed row that hold the
-// pixels' band, reads 4 luminance bytes, writes 16 bytes of RGBA8 built as :694-699 build them.
+// The ranks' luminance planes into RGBA8 frames.  A workgroup takes RM_ASM_ROWS rows of one frame (blockIdx.y;
+// z = frame) and 4 x 256 quads of 4 pixels along them: which rank's part holds a row, and where, is the same for
+// the whole workgroup and comes out of the kernarg segment by scalar loads.  A lane moves 4 luminance bytes in
+// and 16 bytes of RGBA8 out (built as :694-699 build them) per step, neighbouring lanes neighbouring quads, so a
+// wavefront's load is 256 contiguous bytes and its store 1 KiB; the steps of a lane are independent, and the
+// stores bypass the caches (the frame is not read again here).  HBM-bound: 5 B/px.
+#ifndef RM_ASM_ROWS
+#define RM_ASM_ROWS 2
+#endif
+#ifndef RM_ASM_QUADS
+#define RM_ASM_QUADS 4
+#endif
+
+__device__ __forceinline__ uint32_t pixel_of_luminance(uint32_t l8) {
+    const float L = (float)l8;
+    return to_u8(L * RM_MATERIAL_R) | (to_u8(L * RM_MATERIAL_G) << 8) | (to_u8(L * RM_MATERIAL_B) << 16) | 0xff000000u;
+}
+
 __global__ void __launch_bounds__(256)
-assemble_luminance_kernel(const uint8_t* __restrict__ parts, size_t rank_stride, size_t part_pitch, uint32_t width, uint32_t height,
-                          uint32_t band_rows, uint32_t nranks, uint8_t* __restrict__ rgba, size_t pitch) {
-    const uint32_t quads = (width + 3) / 4;
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (uint64_t)quads * height) return;
-    const uint32_t y = (uint32_t)(i / quads), x0 = (uint32_t)(i % quads) * 4;
-    uint32_t r = 0, ly = y;
-    if (band_rows) {
-        const uint32_t band = y / band_rows;
-        r = band % nranks;
-        ly = (band / nranks) * band_rows + y % band_rows;
-    }
-    const uint8_t* src = parts + (size_t)r * rank_stride + (size_t)ly * part_pitch + x0;
-    uint8_t* dst = rgba + (size_t)y * pitch + (size_t)x0 * 4;
-    for (uint32_t k = 0; k < 4 && x0 + k < width; ++k) {
-        const float L = (float)src[k];
-        reinterpret_cast<uint32_t*>(dst)[k] =
-            to_u8(L * RM_MATERIAL_R) | (to_u8(L * RM_MATERIAL_G) << 8) | (to_u8(L * RM_MATERIAL_B) << 16) | 0xff000000u;
+assemble_luminance_kernel(AssembleParams by_value) {
+    (void)by_value;
+    typedef const __attribute__((address_space(4))) AssembleParams Kernarg;
+    Kernarg* kp = (Kernarg*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t width = kp->width, height = kp->height;
+    const uint32_t band_rows = kp->band_rows, frame = blockIdx.z;
+    const bool vector = kp->vector != 0;
+    for (uint32_t y0 = blockIdx.y * RM_ASM_ROWS; y0 < height; y0 += gridDim.y * RM_ASM_ROWS) {
+#pragma unroll
+        for (uint32_t dy = 0; dy < RM_ASM_ROWS; ++dy) {
+            const uint32_t y = y0 + dy;
+            if (y >= height) break;
+            uint32_t r = 0, ly = y;
+            if (band_rows) {
+                const uint32_t band = y / band_rows, period = kp->period, run = band / period, place = band - run * period;
+                r = kp->owner[place];
+                ly = (run * kp->own[r] + kp->index[place]) * band_rows + (y - band * band_rows);
+            }
+            const uint8_t* src_row = kp->parts + (size_t)r * kp->rank_stride + (size_t)frame * kp->part_frame_stride + (size_t)ly * kp->part_pitch;
+            uint8_t* dst_row = kp->rgba + (size_t)frame * kp->rgba_frame_stride + (size_t)y * kp->pitch;
+#pragma unroll
+            for (uint32_t j = 0; j < RM_ASM_QUADS; ++j) {
+                const uint32_t x0 = ((blockIdx.x * RM_ASM_QUADS + j) * 256 + threadIdx.x) * 4;
+                if (x0 >= width) break;
+                const uint8_t* src = src_row + x0;
+                uint8_t* dst = dst_row + (size_t)x0 * 4;
+                if (vector && x0 + 4 <= width) {
+                    const uint32_t l4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src));
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 out;
+                    out.x = pixel_of_luminance(l4 & 0xffu);
+                    out.y = pixel_of_luminance((l4 >> 8) & 0xffu);
+                    out.z = pixel_of_luminance((l4 >> 16) & 0xffu);
+                    out.w = pixel_of_luminance(l4 >> 24);
+                    __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(dst));
+                } else {
+                    for (uint32_t k = 0; k < 4 && x0 + k < width; ++k)
+                        reinterpret_cast<uint32_t*>(dst)[k] = pixel_of_luminance(src[k]);
+                }
+            }
+        }
     }
 }
 
-hipError_t launch_assemble_luminance(const uint8_t* parts, size_t rank_stride, size_t part_pitch, uint32_t width, uint32_t height,
-                                     uint32_t band_rows, uint32_t nranks, uint8_t* rgba, size_t pitch, hipStream_t stream) {
-    const uint64_t threads = (uint64_t)((width + 3) / 4) * height;
-    if (!threads) return hipSuccess;
-    hipLaunchKernelGGL(assemble_luminance_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
-                       parts, rank_stride, part_pitch, width, height, band_rows, nranks, rgba, pitch);
+hipError_t launch_assemble_luminance(const AssembleParams& prm, uint32_t frames, hipStream_t stream) {
+    if (!prm.width || !prm.height || !frames) return hipSuccess;
+    const unsigned quads = (prm.width + 3) / 4, per_block = 256 * RM_ASM_QUADS;
+    const unsigned row_groups = (prm.height + RM_ASM_ROWS - 1) / RM_ASM_ROWS;
+    const dim3 grid((quads + per_block - 1) / per_block, row_groups < 65535u ? row_groups : 65535u, frames);
+    hipLaunchKernelGGL(assemble_luminance_kernel, grid, dim3(256), 0, stream, prm);
     return hipGetLastError();
 }
 

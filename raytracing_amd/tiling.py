@@ -1,30 +1,67 @@
 """Row-band partition of a frame across ranks and its inverse.
 
 The image is cut into bands of `band_rows` rows; band b belongs to rank
-b % nranks.  A rank renders its bands packed top to bottom (rm_set_bands);
-`assemble` interleaves the per-rank buffers back into the frame.  Pixels are
-independent, so the assembled frame equals the single-rank frame byte for byte.
+owner[b % len(owner)] - b % nranks when no pattern is given (rm_set_bands), any
+deal of a run of bands with one (rm_set_band_pattern: a rank with other work gets
+fewer).  A rank renders its bands packed top to bottom; `assemble` interleaves
+the per-rank buffers back into the frame.  Pixels are independent, so the
+assembled frame equals the single-rank frame byte for byte.
 """
 import numpy as np
 
+MAX_PERIOD = 64          # RM_MAX_BAND_PERIOD (include/rm_types.h)
+MAX_OWN = 16             # bands of a run one rank may hold (kernel_params.h RM_MAX_BAND_OWN)
 
-def band_of_rank(height, band_rows, rank, nranks):
+
+def deal(weights):
+    """A run of sum(weights) bands dealt to ranks in proportion to the integer `weights`, each rank's bands
+    spread evenly over the run (the costly middle of the image then falls to every rank alike): the k-th of
+    rank r's w bands is due at (k + 1/2) / w of the run, and bands are handed out in the order they fall due."""
+    weights = [int(w) for w in weights]
+    if not weights or min(weights) < 0 or sum(weights) < 1 or sum(weights) > MAX_PERIOD or max(weights) > MAX_OWN:
+        raise ValueError("band weights %r: need 1..%d bands in all, at most %d per rank" % (weights, MAX_PERIOD, MAX_OWN))
+    due = sorted(((2 * k + 1) / (2.0 * w), r) for r, w in enumerate(weights) for k in range(w))
+    return [r for _, r in due]
+
+
+def lighter_rank0(nranks, rank0_share):
+    """Integer weights (for `deal`) that give rank 0 about `rank0_share` of an even share (1.0: an even deal):
+    w0 : w with w0 / w nearest to it among the runs that fit MAX_PERIOD and MAX_OWN."""
+    if nranks == 1 or rank0_share >= 1.0:
+        return [1] * nranks
+    best = None
+    for w in range(1, MAX_OWN + 1):
+        for w0 in range(0, w + 1):
+            if w0 + w * (nranks - 1) > MAX_PERIOD:
+                continue
+            err = abs(w0 / w - rank0_share)
+            if best is None or err < best[0] - 1e-12:
+                best = (err, w0, w)
+    return [best[1]] + [best[2]] * (nranks - 1)
+
+
+def _owner(nranks, owner):
+    return list(range(nranks)) if owner is None else list(owner)
+
+
+def band_of_rank(height, band_rows, rank, nranks, owner=None):
     """[(y0, y1)] image rows of the bands owned by `rank`, top to bottom."""
+    owner = _owner(nranks, owner)
     out = []
     b = 0
     for y0 in range(0, height, band_rows):
-        if b % nranks == rank:
+        if owner[b % len(owner)] == rank:
             out.append((y0, min(height, y0 + band_rows)))
         b += 1
     return out
 
 
-def local_rows(height, band_rows, rank, nranks):
-    return sum(y1 - y0 for y0, y1 in band_of_rank(height, band_rows, rank, nranks))
+def local_rows(height, band_rows, rank, nranks, owner=None):
+    return sum(y1 - y0 for y0, y1 in band_of_rank(height, band_rows, rank, nranks, owner))
 
 
-def max_local_rows(height, band_rows, nranks):
-    return max(local_rows(height, band_rows, r, nranks) for r in range(nranks))
+def max_local_rows(height, band_rows, nranks, owner=None):
+    return max(local_rows(height, band_rows, r, nranks, owner) for r in range(nranks))
 
 
 def default_band_rows(height, nranks):
@@ -54,7 +91,7 @@ def assemble_into(frame_padded, parts, band_rows):
     return frame_padded
 
 
-def assemble(parts, height, band_rows):
+def assemble(parts, height, band_rows, owner=None):
     """parts[r]: array [>=local_rows(r), width, C] -> frame [height, width, C] (numpy or torch)."""
     nranks = len(parts)
     first = parts[0]
@@ -64,7 +101,7 @@ def assemble(parts, height, band_rows):
         frame = np.zeros((height,) + first.shape[1:], dtype=first.dtype)
     for r in range(nranks):
         at = 0
-        for y0, y1 in band_of_rank(height, band_rows, r, nranks):
+        for y0, y1 in band_of_rank(height, band_rows, r, nranks, owner):
             frame[y0:y1] = parts[r][at:at + (y1 - y0)]
             at += y1 - y0
     return frame

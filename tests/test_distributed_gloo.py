@@ -47,19 +47,22 @@ def _worker(rank, world, port, w, h, band, out_path):
         tiling.assemble_into(frame, parts, band)
         np.save(out_path, frame[:h].numpy())
     # bench.py's transport: one byte per pixel (the blue channel is the luminance), the frames of a
-    # launch in one gather, RGBA8 rebuilt on rank 0 (rm_set_luminance_output / rm_assemble_luminance)
+    # launch in one gather, RGBA8 rebuilt on rank 0 (rm_set_luminance_output / rm_assemble_luminance_batch),
+    # the bands dealt by weight: rank 0, which rebuilds, holds half of what rank 1 does (rm_set_band_pattern)
+    owner = tiling.deal([1, 2])
+    rows_max = tiling.max_local_rows(h, band, world, owner)
     infos = [info, O.default_info(3, 40)]
     slab = torch.zeros((len(infos), rows_max, w), dtype=torch.uint8)
     for f, inf in enumerate(infos):
         at = 0
-        for y0, y1 in tiling.band_of_rank(h, band, rank, world):
+        for y0, y1 in tiling.band_of_rank(h, band, rank, world, owner):
             part = O.render(nodes, w, h, inf, rows=(y0, y1))["rgba"][y0:y1]
             slab[f, at:at + (y1 - y0)] = torch.from_numpy(np.ascontiguousarray(part[:, :, 2]))
             at += y1 - y0
     slabs = torch.zeros((world,) + tuple(slab.shape), dtype=torch.uint8) if rank == 0 else None
     dist.gather(slab, list(slabs.unbind(0)) if rank == 0 else None, dst=0)
     if rank == 0:
-        frames = [tiling.expand_luminance(tiling.assemble([slabs[r, f].numpy()[:, :, None] for r in range(world)], h, band)[:, :, 0])
+        frames = [tiling.expand_luminance(tiling.assemble([slabs[r, f].numpy()[:, :, None] for r in range(world)], h, band, owner)[:, :, 0])
                   for f in range(len(infos))]
         np.save(out_path.replace(".npy", "_lum.npy"), np.stack(frames))
     dist.barrier()

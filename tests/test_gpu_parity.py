@@ -393,6 +393,64 @@ def test_luminance_planes_rebuild_the_frame(stock_scenes, name):
             rm.close()
 
 
+def test_uneven_band_deals_and_the_batched_rebuild(stock_scenes):
+    """rm_set_band_pattern + rm_assemble_luminance_batch: bands dealt by weight (rank 0 fewer, one rank none at
+    all, a rank with several bands of a run), three frames per launch from different cameras, every rank's
+    luminance planes put back together in one kernel, are the frames rendered whole - RGBA8 rows read back
+    per rank too.  Once with planes laid out for the vector path (4-byte loads, 16-byte stores) and once with a
+    pitch that forbids it; the single-frame call must agree with the batch."""
+    torch = pytest.importorskip("torch")
+    from raytracing_amd import tiling
+    nodes = stock_scenes["chair"]
+    w, h, n = 328, 250, 3
+    infos = np.concatenate([O.default_info(k + 1, 9 * k) for k in range(n)])
+    whole = []
+    with api.Raymarching(w, h) as rm:
+        rm.set_nodes(nodes)
+        for k in range(n):
+            rm.set_info(infos[k:k + 1])
+            rm.process()
+            whole.append(rm.read_pixels())
+    assert sum(int(f[:, :, :3].any(-1).sum()) for f in whole) > 3000
+    for weights, band, pitch in [([1, 2, 2], 16, w), ([3, 5, 5, 5, 5, 5, 5, 5], 16, w + 8), ([0, 1, 1, 1], 32, w), ([2, 16], 16, w + 3)]:
+        nranks, owner = len(weights), tiling.deal(weights)
+        rows_max = -(-tiling.max_local_rows(h, band, nranks, owner) // 16) * 16
+        parts = torch.full((nranks, n, rows_max, pitch), 0xAB, dtype=torch.uint8, device="cuda")
+        keep = []
+        for rank in range(nranks):
+            rm = api.Raymarching(w, h)
+            rm.set_nodes(nodes)
+            rm.set_bands(band, rank, nranks, owner)
+            assert rm.local_rows() == tiling.local_rows(h, band, rank, nranks, owner)
+            rm.set_batch(n, 0, rows_max * pitch)
+            rm.set_luminance_output(parts[rank].data_ptr(), pitch)
+            rm.set_info_batch(infos)
+            rm.process()
+            keep.append(rm)
+        rgba_parts = [rm.read_pixels() for rm in keep]                     # frame 0 of the launch, this rank's rows
+        assert np.array_equal(tiling.assemble(rgba_parts, h, band, owner), whole[0]), weights
+        out = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        keep[-1].assemble_luminance_batch(parts.data_ptr(), n * rows_max * pitch, rows_max * pitch, pitch, n,
+                                          out.data_ptr(), w * 4, h * w * 4)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(got[k], whole[k]), (weights, k)
+        one = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        keep[0].assemble_luminance(parts[:, 1].data_ptr(), n * rows_max * pitch, pitch, one.data_ptr(), w * 4)
+        torch.cuda.synchronize()
+        assert np.array_equal(one.cpu().numpy(), whole[1]), weights
+        with pytest.raises(api.RaymarchError):                             # frames that would overlap
+            keep[0].assemble_luminance_batch(parts.data_ptr(), n * rows_max * pitch, rows_max * pitch, pitch, n,
+                                             out.data_ptr(), w * 4, h * w * 4 - 4)
+        for rm in keep:
+            rm.close()
+    with api.Raymarching(w, h) as rm:
+        for owner, rank, nranks in [([0, 1, 2], 0, 2), ([0] * 17 + [1], 0, 2), ([0, 1], 2, 2), ([0] * 65, 0, 1)]:
+            with pytest.raises(api.RaymarchError):
+                rm.set_bands(16, rank, nranks, owner)
+
+
 def test_batch_of_frames_in_one_launch(stock_scenes):
     """rm_set_batch: several frames per launch, their tiles in one pool, equal the frames rendered one
     by one: different cameras, caller-owned planes with a frame stride, row bands, three launches in a

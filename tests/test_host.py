@@ -247,6 +247,32 @@ def test_tiling_partition_covers_every_row_once():
         assert tiling.padded_rows(h, band, n) >= h and tiling.padded_rows(h, band, n) % (band * n) == 0
 
 
+def test_weighted_deals_cover_every_row_once():
+    """tiling.deal / lighter_rank0: bands dealt by weight (rm_set_band_pattern's owner table) still give every
+    row to exactly one rank, in the proportions asked for, each rank's bands spread over the run."""
+    assert tiling.deal([1, 1, 1]) == [0, 1, 2]
+    assert tiling.lighter_rank0(8, 1.0) == [1] * 8 and tiling.lighter_rank0(1, 0.3) == [1]
+    assert tiling.lighter_rank0(8, 0.5) == [1] + [2] * 7 and tiling.lighter_rank0(8, 0.0)[0] == 0
+    w = tiling.lighter_rank0(8, 0.58)
+    assert abs(w[0] / w[1] - 0.58) < 0.03 and sum(w) <= tiling.MAX_PERIOD and max(w) <= tiling.MAX_OWN
+    for weights in ([1, 2, 2], [3, 5, 5, 5, 5, 5, 5, 5], [0, 1, 1, 1], [9, 10], [2, 16]):
+        owner = tiling.deal(weights)
+        assert [owner.count(r) for r in range(len(weights))] == weights
+        for r, wt in enumerate(weights):                       # no rank's bands bunch up: gaps within a factor of two
+            at = [k for k, o in enumerate(owner) if o == r]
+            gaps = [b - a for a, b in zip(at, at[1:] + [at[0] + len(owner)])] if at else [1]
+            assert max(gaps) <= 2 * min(gaps) + 1, (weights, r, owner)
+        for h, band in [(2160, 16), (250, 32), (4320, 16)]:
+            seen = np.zeros(h, dtype=int)
+            for r in range(len(weights)):
+                for y0, y1 in tiling.band_of_rank(h, band, r, len(weights), owner):
+                    seen[y0:y1] += 1
+            assert (seen == 1).all()
+    for bad in ([], [0, 0], [17, 1], [8] * 9):
+        with pytest.raises(ValueError):
+            tiling.deal(bad)
+
+
 def test_cpp_front_end_is_built():
     assert os.path.exists(os.path.join(ROOT, "raytracing_amd", "rm_render")), "run __graft_entry__.build()"
 
@@ -329,11 +355,12 @@ def test_a_launch_that_is_not_full_sets_no_batch(steps, batch, contexts, want):
 
 
 def test_bench_sets_the_batch_once_before_timing():
-    """bench.py itself: rm_set_batch appears once, ahead of the warm-up, and the oracle is imported only
-    for the CPU baseline (the camera block comes from the committed fixture)."""
+    """bench.py itself: rm_set_batch is called ahead of the warm-up only (once per layout: whole frames, or the
+    bands of a deal), and the oracle is imported only for the CPU baseline (the camera block comes from the
+    committed fixture)."""
     with open(os.path.join(ROOT, "bench.py")) as f:
         text = f.read()
-    assert text.count(".set_batch(") == 1 and text.index(".set_batch(") < text.index("# Warm-up")
+    assert text.count(".set_batch(") == 2 and text.rindex(".set_batch(") < text.index("# Warm-up")
     assert text.count("from oracle import") == 1 and text.index("from oracle import") < text.index("def main()")
     blocks = np.fromfile(os.path.join(ROOT, "tests", "golden", "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
     assert blocks[0:1].tobytes() == O.default_info(1, 0).tobytes()
