@@ -230,7 +230,10 @@ def main():
     # N>1: a rank's launch at N=8 then holds four frames' worth of tiles (tools/slice_rate.py, render
     # side only, 3 contexts in flight: 48 k shares/s per GPU at 4K against 6.4 k whole frames/s on one GPU, 11.1 k
     # against 1.43 k at 8K), and at least two launches, so that a gather runs under the next launch's kernel.
-    batch = args.frames_per_launch or 32
+    # A launch of more than ~8 M tiles gains nothing (8K sweep, same box: 0.346-0.348 ms per frame in launches of 8 or
+    # 16, 0.354 of 32 - and on a moving camera the tile order a frame inherits is the older the longer the launch).
+    tiles_per_rank = ((w + 7) // 8) * ((h + 7) // 8) / max(1, world)
+    batch = args.frames_per_launch or max(1, min(32, int((1 << 23) / tiles_per_rank)))
     batch = max(1, min(32, batch))
     # the timed run's launch size is the warm-up's too (70 steps at up to 32 per launch: 24, 23 and 23, and the
     # warm-up's launches hold 24): a launch learns its tile order and its grid from the launch before it

@@ -26,15 +26,18 @@ note = argv[2] if len(argv) > 2 else ""
 scene, W, H = WORKLOADS[workload]
 G = os.path.join(ROOT, "gpurun_out")
 KERNEL = "rm_render_jit"
-PMC_LAUNCHES = 2      # the counter passes run --steps 32 --warmup 16 at 16 frames per launch: the last two launches are the timed ones
+PMC_LAUNCHES = 2      # the counter passes run --steps 64 --warmup 32: a warm-up launch of 32 frames, then the two timed ones, which are the ones counted
 
-lines = ["# %s: %s (%s.sce %dx%d), MI355X, one context, launches of 16 frames back to back; all figures per launch%s" % (tag, workload, scene, W, H, (" -- " + note) if note else ""),
+bench_line = open(os.path.join(G, tag + "_trace_bench.json")).read().strip().splitlines()[-1]
+rec = json.loads(bench_line)
+fpl = int(round(rec["config"].get("frames_per_launch", 1)))
+lines = ["# %s: %s (%s.sce %dx%d), MI355X, one context, launches of %d frames back to back; all figures per launch%s" % (tag, workload, scene, W, H, fpl, (" -- " + note) if note else ""),
          "# command per pass: rocprofv3 [--kernel-trace --stats | --pmc <counters> --kernel-trace] -- python3 bench.py --workload %s --steps K --warmup W --no-cpu-baseline --no-single-frame" % workload,
          "# (tools/profile_round.sh, summarised by tools/profile_summary.py; every counter pass is a run of its own)", ""]
 
 # ---- kernel trace
 db_path = glob.glob(os.path.join(G, tag + "_trace", "**", "*.db"), recursive=True)
-lines.append("## kernel trace (--steps 96 --warmup 16, 16 frames per launch)")
+lines.append("## kernel trace (--steps 96 --warmup 16, %d frames per launch)" % fpl)
 avg_us = None
 if db_path:
     db = sqlite3.connect(db_path[0])
@@ -51,7 +54,6 @@ else:
         if row["Name"].startswith(KERNEL):
             avg_us = float(row["AverageNs"]) / 1e3
 lines.append("")
-bench_line = open(os.path.join(G, tag + "_trace_bench.json")).read().strip().splitlines()[-1]
 lines += ["## bench line of the traced run", bench_line, ""]
 
 # ---- counters: mean per launch over the timed launches
@@ -72,8 +74,6 @@ for name, v in counters.items():
 lines.append("")
 
 # ---- derived
-rec = json.loads(bench_line)
-fpl = int(round(rec["config"].get("frames_per_launch", 1)))
 rays = W * H * fpl                            # per launch
 lines.append("## derived")
 if "GRBM_GUI_ACTIVE" in counters:
