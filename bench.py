@@ -336,10 +336,10 @@ def main():
         # The deal.  For each candidate share of rank 0 every rank runs its part of the job without the collective
         # - its bands rendered in launches on its contexts in turn, rank 0 rebuilding every launch's frames beside
         # them - and reports frames per second; the job runs at its slowest rank's rate, and the candidate where
-        # that is highest is taken.  (Measured rather than modelled: the rebuild costs rank 0 more than it takes
-        # alone, its workgroups wait for slots the persistent render wavefronts hold; one GPU, tools/slice_rate.py,
-        # 8 ranks at 4K: even deal 33 k frames/s on rank 0 against 45 k on the others, a quarter share 55 k
-        # against 44 k.)
+        # that is highest is taken.  (Measured rather than modelled: rank 0's time is not its share times a rate plus
+        # the rebuild's time alone - a launch is never shorter than its longest ray, and the two kernels share the
+        # chip.  One GPU, tools/slice_rate.py, 8 ranks at 4K: even deal 33 k frames/s on rank 0 against 45 k on the
+        # others, half a share 38 k against 42 k, a quarter share 55 k against 44 k.)
         shares = (1.0, 0.75, 0.5, 0.375, 0.25, 0.125)
         lay["gather"] = False
         table = []
