@@ -392,6 +392,9 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     run.launches = 0
     run.plan(args.steps)                               # launches of nearly equal size
+    import gc
+    gc.collect()
+    gc.disable()                                       # a 20-step run is 3 ms long: no collector pause inside it
     t0 = time.perf_counter()
     ev0.record(streams[run.ctx])
     for k in range(args.steps):
@@ -403,6 +406,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     secs = time.perf_counter() - t0
+    gc.enable()
     launches = max(1, run.launches)
     if host_times:
         print("host time per after_launch (gather + rebuild), last %d: median %.1f us" % (
