@@ -121,7 +121,7 @@ int rm_set_info_batch(rm_ctx* ctx, const rm_rays_info* infos, size_t n);
 
 /* Multi-GPU row bands (no counterpart: the reference is single-device,
  * Source/cuda_rays.cu:20-21).  The image is cut into bands of `band_rows` rows
- * (a multiple of 16); this context renders bands b with b % nranks == rank,
+ * (a multiple of 8, the tile height); this context renders bands b with b % nranks == rank,
  * packed top to bottom into its output buffer.  rm_local_rows reports how many
  * rows that is.  band_rows = 0 restores whole-frame rendering.
  * rm_set_band_pattern deals the bands unevenly: owner[k] (k < period <=

@@ -677,7 +677,7 @@ int rm_set_batch(rm_ctx* c, size_t frames, size_t rgba_frame_stride_bytes, size_
 int rm_set_band_pattern(rm_ctx* c, size_t band_rows, const unsigned char* owner, size_t period, int rank, int nranks) {
     if (!c) return RM_ERR_INVALID_ARG;
     if (band_rows != 0) {
-        if ((band_rows % 16) || !owner || period < 1 || period > RM_MAX_BAND_PERIOD || nranks < 1 || nranks > RM_MAX_BAND_PERIOD ||
+        if ((band_rows % 8) || !owner || period < 1 || period > RM_MAX_BAND_PERIOD || nranks < 1 || nranks > RM_MAX_BAND_PERIOD ||
             rank < 0 || rank >= nranks) return RM_ERR_INVALID_ARG;
         size_t mine = 0;
         for (size_t k = 0; k < period; ++k) {

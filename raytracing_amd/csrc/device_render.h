@@ -261,7 +261,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         uint32_t gy = ly;                                                    // row in the image
         const uint32_t band_rows = tp->band_rows, width = tp->width, height = tp->height;
         if (band_rows) {
-            // bands are multiples of 16 rows (rm_set_bands) and a tile is 8 rows high: a tile lies in one band, and
+            // bands are multiples of 8 rows (rm_set_bands) and a tile is 8 rows high: a tile lies in one band, and
             // which one is the same for all its lanes - a scalar division, not one per lane
             // (the context's band-th band is the image's: run * band_period + band_slot[k], rm_set_band_pattern)
             const uint32_t ly0 = tile_y * 8, band = ly0 / band_rows, own = tp->band_own;

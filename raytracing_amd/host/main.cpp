@@ -6,7 +6,7 @@
 //   rm_render --width W --height H [--input scene.sce] [--frames K] [--drag-x PX] [--drag-y PX] [--script events.txt]
 //             [--out frame.ppm] [--device D] [--gpus N] [--devices D0,D1,...]
 //
-// --gpus N: the frame is dealt to N GPUs in 16-row bands (hip::raymarching over several devices, rays.hpp; D,
+// --gpus N: the frame is dealt to N GPUs in 8-row bands (hip::raymarching over several devices, rays.hpp; D,
 // D+1, ... unless --devices names them, and a device named twice gets two contexts); every frame is rendered by
 // all of them and the PPM is the frame put together from their rows.
 //

@@ -157,7 +157,7 @@ namespace hip {
 // every frame from the same scene and camera block, nothing is exchanged between them, and ReadPixels() puts
 // the bands back in frame order on the host.  A device may be named more than once (several contexts on one
 // GPU): that is how the path is tested on a one-GPU box.
-constexpr size_t RM_FRONT_END_BAND_ROWS = 16;
+constexpr size_t RM_FRONT_END_BAND_ROWS = 8;      // one row of tiles: the finest deal
 
 class raymarching : public null::raymarching {
     std::vector<rm_ctx*> ctx_;

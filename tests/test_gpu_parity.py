@@ -345,7 +345,7 @@ def test_row_bands_reassemble(stock_scenes):
     info = O.default_info(1, 0)
     w, h = 320, 250
     whole, _, _ = gpu_render(stock_scenes["chair"], w, h, info)
-    for nranks, band in [(2, 16), (3, 32), (8, 16)]:
+    for nranks, band in [(2, 16), (3, 32), (8, 16), (5, 8), (3, 24)]:
         parts = []
         for rank in range(nranks):
             with api.Raymarching(w, h) as rm:
@@ -412,7 +412,7 @@ def test_uneven_band_deals_and_the_batched_rebuild(stock_scenes):
             rm.process()
             whole.append(rm.read_pixels())
     assert sum(int(f[:, :, :3].any(-1).sum()) for f in whole) > 3000
-    for weights, band, pitch in [([1, 2, 2], 16, w), ([3, 5, 5, 5, 5, 5, 5, 5], 16, w + 8), ([0, 1, 1, 1], 32, w), ([2, 16], 16, w + 3)]:
+    for weights, band, pitch in [([1, 2, 2], 16, w), ([3, 5, 5, 5, 5, 5, 5, 5], 8, w + 8), ([0, 1, 1, 1], 32, w), ([2, 16], 8, w + 3)]:
         nranks, owner = len(weights), tiling.deal(weights)
         rows_max = -(-tiling.max_local_rows(h, band, nranks, owner) // 16) * 16
         parts = torch.full((nranks, n, rows_max, pitch), 0xAB, dtype=torch.uint8, device="cuda")
@@ -449,6 +449,9 @@ def test_uneven_band_deals_and_the_batched_rebuild(stock_scenes):
         for owner, rank, nranks in [([0, 1, 2], 0, 2), ([0] * 17 + [1], 0, 2), ([0, 1], 2, 2), ([0] * 65, 0, 1)]:
             with pytest.raises(api.RaymarchError):
                 rm.set_bands(16, rank, nranks, owner)
+        for band in (4, 12, 20):                                            # a band is whole rows of 8x8 tiles
+            with pytest.raises(api.RaymarchError):
+                rm.set_bands(band, 0, 2)
 
 
 def test_batch_of_frames_in_one_launch(stock_scenes):
@@ -791,7 +794,7 @@ def test_front_end_ppm_matches_reference_hash(name, golden_dir, tmp_path):
 
 @pytest.mark.parametrize("gpus,height", [(2, 480), (3, 250), (8, 1080)])
 def test_front_end_several_gpu_contexts(gpus, height, stock_scenes, golden_dir, tmp_path):
-    """rm_render --gpus N: the frame dealt in 16-row bands to N contexts (here all on this GPU, --devices 0,0,...:
+    """rm_render --gpus N: the frame dealt in 8-row bands to N contexts (here all on this GPU, --devices 0,0,...:
     the box has one), three frames along config 5's camera path, put together on the host.  The PPM must be the
     one-context front end's, which is the oracle's frame; 250 rows leave a last band of 10 and ranks of unequal
     height, 1080 rows give rank 0 one band more than the others."""
