@@ -163,6 +163,11 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     if (c->band_rows)
         for (size_t k = 0; k < c->band_period; ++k)
             if (c->band_owner[k] == c->rank && p.band_own < RM_MAX_BAND_OWN) p.band_slot[p.band_own++] = static_cast<uint32_t>(k);
+    const size_t tile_rows = c->band_rows / 8;
+    p.band_shift = ~0u;
+    if (tile_rows && (tile_rows & (tile_rows - 1)) == 0)
+        for (p.band_shift = 0; (size_t{1} << p.band_shift) < tile_rows;) ++p.band_shift;
+    p.band_own_magic = p.band_own > 1 ? static_cast<uint32_t>(((uint64_t{1} << 32) + p.band_own - 1) / p.band_own) : 0u;
     p.evaluator = c->evaluator;
     p.rgba = c->out; p.pitch = c->out_pitch;
     p.hit = c->hit;  p.hit_pitch = c->width;

@@ -264,9 +264,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             // bands are multiples of 8 rows (rm_set_bands) and a tile is 8 rows high: a tile lies in one band, and
             // which one is the same for all its lanes - a scalar division, not one per lane
             // (the context's band-th band is the image's: run * band_period + band_slot[k], rm_set_band_pattern)
-            const uint32_t ly0 = tile_y * 8, band = ly0 / band_rows, own = tp->band_own;
+            const uint32_t ly0 = tile_y * 8, shift = tp->band_shift, own = tp->band_own;
+            const uint32_t band = shift != ~0u ? tile_y >> shift : ly0 / band_rows;
             uint32_t run = band, k = 0;
-            if (own > 1) { run = band / own; k = band - run * own; }
+            if (own > 1) { run = (uint32_t)(((uint64_t)band * tp->band_own_magic) >> 32); k = band - run * own; }
             gy = (run * tp->band_period + tp->band_slot[k]) * band_rows + (ly0 - band * band_rows) + (lane >> 3);
         }
         const bool in_image = px < width && gy < height && ly < tp->local_rows;

@@ -97,6 +97,9 @@ struct RenderParams {
     // ones at places band_slot[0..band_own) of the run, packed top to bottom (rm_set_bands: band_period = nranks,
     // band_own = 1, band_slot[0] = rank)
     uint32_t band_rows, band_period, band_own;
+    // the two divisions of a tile's band lookup, prepared by the host: band_rows / 8 as a shift when it is a power of
+    // two (else ~0u: divide), and ceil(2^32 / band_own), whose high product with a band number below 2^28 is the quotient
+    uint32_t band_shift, band_own_magic;
     uint32_t band_slot[RM_MAX_BAND_OWN];
     uint32_t evaluator;           // 0 distance program, 1 tree walker
     uint32_t nframes;             // frames of this launch (rm_set_batch): tile ids run over all of them

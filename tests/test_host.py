@@ -273,6 +273,18 @@ def test_weighted_deals_cover_every_row_once():
             tiling.deal(bad)
 
 
+def test_band_lookup_magic_is_exact():
+    """fill_params hands the kernel ceil(2^32 / own) so that a tile finds its run of bands with a high multiply
+    (device_render.h): exact for every band number an image can have (fewer than 2^27 bands of 8 rows in 2^30
+    pixels; shown for band < 2^28 since band * (own * magic - 2^32) < 2^32)."""
+    for own in range(2, 17):
+        magic = ((1 << 32) + own - 1) // own
+        assert (own * magic - (1 << 32)) * ((1 << 28) - 1) < (1 << 32)
+        edge = [own * k + d for k in (1, 2, 3, 1000, (1 << 27) // own, ((1 << 28) - 1) // own) for d in (-1, 0, 1)]
+        for band in list(range(4096)) + [b for b in edge if 0 <= b < (1 << 28)]:
+            assert (band * magic) >> 32 == band // own, (own, band)
+
+
 def test_cpp_front_end_is_built():
     assert os.path.exists(os.path.join(ROOT, "raytracing_amd", "rm_render")), "run __graft_entry__.build()"
 
