@@ -340,7 +340,7 @@ def main():
         # the rebuild's time alone - a launch is never shorter than its longest ray, and the two kernels share the
         # chip.  One GPU, tools/slice_rate.py, 8 ranks at 4K: even deal 33 k frames/s on rank 0 against 45 k on the
         # others, half a share 38 k against 42 k, a quarter share 55 k against 44 k.)
-        shares = (1.0, 0.75, 0.5, 0.375, 0.25, 0.125)
+        shares = (1.0, 0.875, 0.75, 0.5, 0.375, 0.25, 0.125)
         lay["gather"] = False
         table = []
         for share in shares:
