@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="timed blocks of --steps frames, back to back; the median block is reported (>= 1)")
     ap.add_argument("--workload", default="chair_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for N>1 (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,6 +241,13 @@ def main():
     # warm-up's launches hold 24): a launch learns its tile order and its grid from the launch before it
     if args.steps > 0:
         n_launches = max(-(-args.steps // batch), min(2, args.steps) if multi else 1)
+        # launches of ONE size where a few more of them allow it (200 steps at up to 32: 8 of 25, not 4 of 29 and 3 of
+        # 28): the timed blocks repeat, and a launch of more frames than the one before it finds the tiles of the
+        # extra frames in no list (they go out last, in natural order: 29 behind 28 measured 6.7 ms against 4.5)
+        for n in range(n_launches, n_launches + n_launches // 2 + 1):
+            if args.steps % n == 0:
+                n_launches = n
+                break
         batch = -(-args.steps // n_launches)
     weights, deal_note = None, None
     if multi:
@@ -292,10 +301,15 @@ def main():
             streams[j].wait_event(gathered[j])         # context j's slab is free again
 
     host_times = [] if os.environ.get("RM_BENCH_HOST_TIMES") else None     # seconds of host time per after_launch
+    launch_marks = None                                # set for the timed part
 
     def after_launch(j, n):
         """N>1: the launch's luminance planes to rank 0 in one gather, RGBA8 frames rebuilt there."""
         if not multi:
+            if launch_marks is not None:               # the timed part, one stream: an event behind every launch
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(streams[j])
+                launch_marks.append(e)
             return
         t_host = time.perf_counter()
         rendered[j].record(streams[j])
@@ -368,6 +382,9 @@ def main():
     # box needs a few hundred milliseconds of work before its clocks are where a long run has them, and the
     # tile order is learnt from the launch before.  Every rank runs the same number of launches (the
     # gathers are collective), so the ranks agree on the count.
+    import gc
+    gc.collect()                                       # now, while nothing is timed: the chip must not sit idle between
+    gc.disable()                                       # the warm-up and the timed blocks, and no collector pause falls into them
     warm = -(-args.warmup // batch) * batch
     t_warm = time.perf_counter()
     for k in range(warm):
@@ -385,44 +402,74 @@ def main():
             step(warm + k)
         warm += 4 * batch * in_flight
         drain()
+    # The timed part (raytracing_amd/batching.py run_blocks): the collector ran before the warm-up; behind
+    # the barrier and synchronize the contract asks for, one block of --steps frames that is NOT timed and
+    # --repeats timed blocks of exactly --steps frames each, every block queued straight behind the one before -
+    # no wait, no collector, no allocation between them - and the barrier and synchronize again.  A block's time
+    # is taken on the device, between the events that follow its last launch and the previous block's (on every
+    # stream that carries its work; the latest one counts), the MAX over ranks per block, and `ms_per_step` /
+    # `value` are the MEDIAN block's.  Round 2 timed one block behind a drain: the chip had been idle for the
+    # milliseconds of the drain, the collector and the barrier, and that one launch read 17 % slower on the
+    # driver's box than the same launch in a row of them (`first_block_ms` is the block that
+    # starts on the idle chip, reported so that the effect stays visible).
+    from raytracing_amd.batching import run_blocks
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timed_streams = list(streams) + ([comm_stream] if multi else [])
+    launch_marks = [] if in_flight == 1 and not multi else None      # one stream: an event behind every launch
+
+    def mark():
+        evs = []
+        for st in timed_streams:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            evs.append(e)
+        return evs
+
+    def info_of(k):
+        return info if sweep is None else sweep[k % len(sweep):k % len(sweep) + 1]
+
     run.launches = 0
-    run.plan(args.steps)                               # launches of nearly equal size
-    import gc
-    gc.collect()
-    gc.disable()                                       # a 20-step run is 3 ms long: no collector pause inside it
     t0 = time.perf_counter()
-    ev0.record(streams[run.ctx])
-    for k in range(args.steps):
-        step(warm + k)
-    run.flush()                                        # exactly --steps frames: the last launch may hold fewer
-    ev1.record(streams[run.last[0]])
+    start = mark()
+    marks, _ = run_blocks(run, info_of, args.steps, args.repeats, mark, first=warm)
     drain()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
-    secs = time.perf_counter() - t0
+    wall = time.perf_counter() - t0
     gc.enable()
-    launches = max(1, run.launches)
+    launches = max(1, run.launches // (args.repeats + 1))            # per block
     if host_times:
         print("host time per after_launch (gather + rebuild), last %d: median %.1f us" % (
             launches, 1e6 * sorted(host_times[-launches:])[launches // 2]), file=sys.stderr)
-    # One context: the kernel's average duration (launch to launch on its stream).  With several
-    # in flight kernels overlap; the region's time per launch is what counts then.
-    kernel_ms = (ev0.elapsed_time(ev1) if in_flight == 1 else secs * 1e3) / launches
+    # when each block ended, in ms after `start` (the latest of its streams)
+    ends = [max(s0.elapsed_time(e) for s0, e in zip(start, evs)) for evs in marks]
+    block_ms = [b - a for a, b in zip(ends[:-1], ends[1:])]         # the timed blocks; ends[0] closes the untimed one
+    first_block_ms = ends[0]
+    if multi:
+        tmax = torch.tensor(block_ms + [first_block_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        block_ms, first_block_ms = [float(x) for x in tmax[:-1].cpu()], float(tmax[-1])
+    order = sorted(range(len(block_ms)), key=lambda r: block_ms[r])
+    mid = order[(len(order) - 1) // 2]                               # the median block (the lower one of two)
+    secs = block_ms[mid] * 1e-3
+    # One context: every launch's own duration (event behind it against the event behind the one before).  With
+    # several in flight kernels overlap; the block's time per launch is what counts then.
+    kernel_ms_all = None
+    if launch_marks is not None:
+        edges = [start[0]] + launch_marks
+        kernel_ms_all = [a.elapsed_time(b) for a, b in zip(edges[:-1], edges[1:])]
+        mine = kernel_ms_all[(mid + 1) * launches:(mid + 2) * launches]
+        kernel_ms = sum(mine) / len(mine)
+    else:
+        kernel_ms = block_ms[mid] / launches
     if not multi:
         frame = frames[run.last[0]][run.last[1]]
     elif rank == 0:
         frame = frames_out[run.last[1]]
-
-    if multi:
-        tmax = torch.tensor([secs], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        secs = float(tmax.item())
 
     if rank == 0:
         got = frame.cpu().numpy()
@@ -436,6 +483,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_frames_run": warm,
             "ms_per_step": secs * 1e3 / args.steps,
             "frames_per_s": args.steps / secs,
+            # --repeats timed blocks of --steps frames each, back to back behind an untimed one: the median block is
+            # `ms_per_step` and `value`; the others, the block that started on the idle chip, and the wall clock over
+            # all repeats + 1 blocks (barrier and synchronize on both sides) are here to check it against
+            "repeats": args.repeats, "block_ms": block_ms,
+            "ms_per_step_min": min(block_ms) / args.steps, "ms_per_step_max": max(block_ms) / args.steps,
+            "first_block_ms": first_block_ms,
+            "wall_ms_per_step_all_blocks": wall * 1e3 / (args.steps * (args.repeats + 1)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, **({"rehearsal": True} if rehearsal else {}),
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s.sce %dx%d, main.cpp default camera, light +1 deg, one primary ray per pixel" % (scene, w, h),
@@ -449,6 +503,7 @@ def main():
                        "golden_hit_pixels": want["hits"] if want else None,
                        "frame_matches_golden": (sha == want["rgba_sha256"]) if want else None},
             "kernel_ms": kernel_ms, "launches": launches,
+            **({"kernel_ms_per_launch": kernel_ms_all} if kernel_ms_all else {}),
         }
         if want:
             # FLOPs of one launch (1/N of each of its frames), counted by the CPU restatement.

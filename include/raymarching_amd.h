@@ -172,8 +172,11 @@ int rm_enable_hit_mask(rm_ctx* ctx, int enable);
 int rm_process(rm_ctx* ctx, float* elapsed_ms);
 
 /* rm_process for callers that cannot allocate.  It has no counterpart in the
- * reference: it is for code under HIP graph capture, tight serving loops and
- * harnesses that forbid hipMalloc.  One frame of the context's scene, camera
+ * reference: it is for tight serving loops, harnesses that forbid hipMalloc and
+ * code that renders between two graph launches without touching the allocator.
+ * (It is NOT itself capturable into a HIP graph: like rm_process it records
+ * events, copies its completion counters to the host and waits for the stream,
+ * none of which a capturing stream allows.)  One frame of the context's scene, camera
  * `info`, into the caller's DEVICE buffer (RGBA8 rows `pitch_bytes` apart, as
  * rm_set_output), waited for like rm_process, same pixels.  The call itself
  * allocates nothing: the tile scheduler's scratch (counter sets, tile lists,
@@ -184,8 +187,9 @@ int rm_process(rm_ctx* ctx, float* elapsed_ms);
  * 3840x2160 frame fits, 7680x4320 does not -> RM_ERR_TOO_LARGE); no hit mask, no
  * luminance plane.  All calls on one GPU share that GPU's array (the tile order
  * learnt by one call serves the next one of the same image size): calls of one
- * process take their turn under a lock; anything else that overlaps on one GPU
- * races. */
+ * process on one GPU take their turn under that GPU's lock, held until the frame
+ * is in (calls on different GPUs run side by side); anything else that overlaps
+ * on one GPU - another process, the same array - races. */
 int rm_process_static(rm_ctx* ctx, const rm_rays_info* info, void* device_rgba, size_t pitch_bytes, float* elapsed_ms);
 
 /* Same launch without events and without waiting: for back-to-back frames
@@ -300,8 +304,8 @@ int rm_set_evaluator(rm_ctx* ctx, int which);
 
 /* Diagnostics: render one launch and return, per (persistent) wavefront, 8
  * dwords: march loop trips, normal passes, clock ticks in the kernel, ticks in
- * normal passes, the low words of the clock (s_memtime, 100 MHz) when the
- * wavefront started and when it left, tiles rendered, trips of its longest tile.
+ * normal passes, the low words of the 100 MHz clock all XCDs share (s_memrealtime)
+ * when the wavefront started and when it left, tiles rendered, trips of its longest tile.
  * With host_out NULL only *n_waves is set. */
 int rm_debug_wave_stats(rm_ctx* ctx, uint32_t* host_out, size_t cap_waves, size_t* n_waves);
 

@@ -58,3 +58,22 @@ class FrameBatcher:
         self.ctx, self.pending = (j + 1) % len(self.ctxs), 0
         if self.after:
             self.after(j, n)
+
+
+def run_blocks(run, info_of, steps, repeats, mark, first=0):
+    """The measured part of bench.py: one block of `steps` frames that is not timed, then `repeats` timed blocks
+    of the same shape straight behind it, every block planned into the same launches (FrameBatcher.plan).
+    Nothing here waits for the device, collects garbage or allocates on it: a block's launches are queued
+    directly behind the block before, so no block but the first starts on an idle chip (round 2's single timed
+    launch followed a drain and read 17 % slow on the driver's box).  `mark()` is called after each block's last
+    launch has been queued (it records events on the streams; it must not wait) and its results are returned:
+    repeats + 1 marks, block r's time is mark r+1 against mark r.  Returns (marks, next frame number)."""
+    marks, k = [], first
+    for _ in range(repeats + 1):
+        run.plan(steps)
+        for _ in range(steps):
+            run.step(info_of(k))
+            k += 1
+        run.flush()
+        marks.append(mark())
+    return marks, k

@@ -61,6 +61,8 @@ struct rm_ctx {
     uint32_t seq = 0;                 // launch sequence number
     uint32_t list_cap = 0, overflow_cap = 0;
     bool adaptive_grid = true;        // the grid follows the previous launch's work and longest tile (render_blocks)
+    size_t tiles_per_wave = 8;        // grid: at least this many tiles per wavefront (RM_TILES_PER_WAVE, read by rm_create)
+    size_t blocks_per_cu_forced = 0;  // experiments (RM_BLOCKS_PER_CU, read by rm_create): 0 = what the kernel's occupancy allows
     bool feedback = true;             // launches file their tiles by cost for the next launch
     bool history = false;             // the previous launch did, with the same tile numbering...
     size_t history_frames = 0;        // ...for this many frames: a launch of more frames starts in natural order
@@ -69,10 +71,9 @@ struct rm_ctx {
     uint32_t* status_host = nullptr;  // pinned copy of the device's status block
     uint32_t expected_done = 0;
     // what the last checked launches measured (judge_status), for the next launch's grid (render_blocks)
-    uint32_t trips_seen = 0;          // running sum of march-loop trips at the last check
-    uint32_t launches_unchecked = 0;  // launches since then
-    size_t unchecked_tiles = 0;       // their tiles
-    double trips_per_tile = 0;        // mean of the launches last checked (0: nothing measured yet)
+    uint32_t launches_unchecked = 0;  // launches since the last check
+    size_t last_tiles = 0;            // tiles of the last launch
+    double trips_per_tile = 0;        // mean of the last launch checked (0: nothing measured yet)
     uint32_t longest_tile = 0;        // trips of the longest tile of the last launch checked
     uint32_t last_slot = 0;           // RM_STATUS_LONGEST slot of the last launch
     uint32_t boost_age = 48;
@@ -148,6 +149,9 @@ void point_at_schedule(rm::RenderParams& p, uint32_t* sched, uint32_t seq, uint3
     p.stat_slot = seq & 1u;
 }
 
+// tiles of one frame of this context (its local rows)
+size_t local_tiles(const rm_ctx* c) { return ((c->width + 7) / 8) * ((c->local_rows + 7) / 8); }
+
 void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     std::memset(&p, 0, sizeof p);
     p.program = c->d_program;
@@ -187,8 +191,10 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     point_at_schedule(p, c->sched, c->seq, c->list_cap, c->overflow_cap);
     p.feedback = c->feedback ? 1u : 0u;
     // the lists of the previous launch hold the tiles of its frames: a launch of fewer frames skips the
-    // entries beyond its own, a launch of more frames would miss tiles
-    p.ordered = (c->feedback && c->history && c->nframes <= c->history_frames) ? 1u : 0u;
+    // entries beyond its own, a launch of more frames takes the tiles of the frames beyond them in natural
+    // order behind the lists (hist_tiles: the ids the lists hold)
+    p.ordered = (c->feedback && c->history) ? 1u : 0u;
+    p.hist_tiles = static_cast<uint32_t>(local_tiles(c) * std::min(c->nframes, c->history_frames));
 }
 
 size_t sched_bytes(const rm_ctx* c) { return sched_dwords(c->list_cap, c->overflow_cap) * sizeof(uint32_t); }
@@ -200,8 +206,6 @@ hipError_t reset_schedule(rm_ctx* c) {
     return hipMemsetAsync(c->sched, 0, 3 * RM_SET_DWORDS * sizeof(uint32_t), c->stream);
 }
 
-// persistent grid: what the chip holds at once, or fewer when the image has few tiles
-size_t local_tiles(const rm_ctx* c) { return ((c->width + 7) / 8) * ((c->local_rows + 7) / 8); }
 
 // A launch is as long as its longest tile (one wavefront, a chain of dependent steps) or as its work spread
 // over the chip, whichever is more, and a wavefront is the faster the fewer share its SIMD: with `trips`
@@ -219,15 +223,12 @@ unsigned render_blocks(const rm_ctx* c, bool jit, size_t frames) {
     // find every queue head dry at the end is small beside its work: a share of a frame (row bands
     // on 8 ranks) must not launch a wavefront per two tiles, and a smaller grid leaves room for the
     // kernels of other frames in flight.
-    size_t tiles_per_wave = 8;
-    if (const char* env = std::getenv("RM_TILES_PER_WAVE"))  // experiments only
-        if (std::atoi(env) > 0) tiles_per_wave = static_cast<size_t>(std::atoi(env));
+    const size_t tiles_per_wave = c->tiles_per_wave;
     const size_t want = (tiles + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
     size_t per_cu = static_cast<size_t>(jit ? c->jit.blocks_per_cu : c->blocks_per_cu);
-    if (const char* env = std::getenv("RM_BLOCKS_PER_CU"))   // experiments only
-        if (std::atoi(env) > 0) per_cu = static_cast<size_t>(std::atoi(env));
+    if (c->blocks_per_cu_forced) per_cu = c->blocks_per_cu_forced;
     size_t resident = static_cast<size_t>(c->cus) * per_cu;
-    if (!std::getenv("RM_BLOCKS_PER_CU") && c->adaptive_grid) {
+    if (!c->blocks_per_cu_forced && c->adaptive_grid) {
         const size_t waves = wanted_waves(c, tiles);                     // ~0 when nothing has been measured yet
         const size_t by_work = waves > 4 * resident ? resident : (waves + 3) / 4;
         const size_t floor = static_cast<size_t>(c->cus) * 2;            // never below two workgroups per CU
@@ -249,7 +250,7 @@ int launch_frame(rm_ctx* c, uint32_t* wave_stats, size_t* waves) {
     if (e == hipSuccess) {
         c->history = c->feedback; c->history_frames = c->nframes;
         c->expected_done += static_cast<uint32_t>(local_tiles(c) * c->nframes);
-        ++c->launches_unchecked; c->unchecked_tiles += local_tiles(c) * c->nframes;
+        ++c->launches_unchecked; c->last_tiles = local_tiles(c) * c->nframes;
         c->last_slot = c->seq & 1u;
         ++c->seq;
     }
@@ -264,19 +265,19 @@ hipError_t fetch_status(rm_ctx* c) {
     return hipMemcpyAsync(c->status_host, status_block(c), RM_STATUS_DWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
 }
 int judge_status(rm_ctx* c) {
-    uint32_t done = 0, trips = 0, longest = 0;
+    uint32_t done = 0, longest = 0;
+    uint64_t trips = 0;               // of the last launch alone (its slot): no running sum that could wrap between checks
     for (int k = 0; k < RM_STATUS_COUNTERS; ++k) {
         const uint32_t* line = c->status_host + k * RM_STATUS_STRIDE;
         done += line[0];
-        trips += line[RM_STATUS_TRIPS];
+        trips += line[RM_STATUS_TRIPS + c->last_slot];
         if (line[RM_STATUS_LONGEST + c->last_slot] > longest) longest = line[RM_STATUS_LONGEST + c->last_slot];
     }
     if (c->launches_unchecked) {
-        c->trips_per_tile = c->unchecked_tiles ? static_cast<double>(trips - c->trips_seen) / static_cast<double>(c->unchecked_tiles) : 0;
+        c->trips_per_tile = c->last_tiles ? static_cast<double>(trips) / static_cast<double>(c->last_tiles) : 0;
         c->longest_tile = longest;
-        c->launches_unchecked = 0; c->unchecked_tiles = 0;
+        c->launches_unchecked = 0;
     }
-    c->trips_seen = trips;
     if (done == c->expected_done && c->status_host[RM_STATUS_FLAG] == 0) return RM_OK;
     c->trips_per_tile = 0; c->longest_tile = 0;
     c->expected_done = done;
@@ -423,8 +424,10 @@ int grow_framebuffer(rm_ctx* c, size_t frames) {
 // ---- rm_process_static: the scheduler block in the library's file-scope device array ----------
 // One per device (raymarch_kernels.hip: static_scratch_address).  Every call on a device shares that
 // device's block, so the state that says what the block holds is per device too, and the calls of
-// one process take their turn under one lock.
+// one process on one device take their turn under that device's lock (calls on different devices do
+// not wait for each other; g_static_mutex only guards the map itself).
 struct StaticSched {
+    std::mutex mu;                    // held for a whole rm_process_static call on this device
     uint32_t* ptr = nullptr;          // device address of this device's copy of the array
     uint32_t seq = 0;                 // launches so far (the counter sets rotate as a context's do)
     bool history = false;             // the lists of launch seq-1 hold every tile of a frame of...
@@ -462,7 +465,10 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     rm_ctx* c = new (std::nothrow) rm_ctx;
     if (!c) return static_cast<int>(hipErrorOutOfMemory);
     c->device = device; c->width = width; c->height = height;
-    if (const char* env = std::getenv("RM_ADAPTIVE_GRID")) c->adaptive_grid = std::atoi(env) != 0;      // experiments only
+    // experiment knobs, read here once: nothing on the launch path looks at the environment
+    if (const char* env = std::getenv("RM_ADAPTIVE_GRID")) c->adaptive_grid = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RM_TILES_PER_WAVE")) if (std::atoi(env) > 0) c->tiles_per_wave = static_cast<size_t>(std::atoi(env));
+    if (const char* env = std::getenv("RM_BLOCKS_PER_CU")) if (std::atoi(env) > 0) c->blocks_per_cu_forced = static_cast<size_t>(std::atoi(env));
     if (const char* env = std::getenv("RM_RAY_WINDOWS")) c->ray_windows = std::atoi(env) != 0;          // experiments only
     if (const char* env = std::getenv("RM_JIT")) c->jit_mode = std::atoi(env) < 0 ? 0 : std::atoi(env) > 3 ? 3 : std::atoi(env);
     hipError_t e = hipStreamCreate(&c->own_stream);
@@ -493,8 +499,10 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     }
     // rm_process_static's scheduler block: its address on this device, looked up once, here at set-up
     {
-        std::lock_guard<std::mutex> lock(g_static_mutex);
-        StaticSched& st = g_static[device];
+        StaticSched* found = nullptr;
+        { std::lock_guard<std::mutex> lock(g_static_mutex); found = &g_static[device]; }      // (map nodes never move)
+        StaticSched& st = *found;
+        std::lock_guard<std::mutex> lock(st.mu);
         if (!st.ptr) {
             hipError_t se = rm::static_scratch_address(device, &st.ptr);
             if (se == hipSuccess) se = hipMemset(st.ptr, 0, (3 * RM_SET_DWORDS) * sizeof(uint32_t));
@@ -529,8 +537,16 @@ int rm_destroy(rm_ctx* c) {
 
 int rm_set_stream(rm_ctx* c, void* hip_stream) {
     if (!c) return RM_ERR_INVALID_ARG;
-    c->stream = static_cast<hipStream_t>(hip_stream);
-    return RM_OK;
+    hipStream_t to = static_cast<hipStream_t>(hip_stream);
+    if (to == c->stream) return RM_OK;
+    // Completion accounting and the scheduler's counter sets follow stream order: launches still in flight on the
+    // old stream are waited for (and checked) before anything is queued on the new one.
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(fetch_status(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int rc = judge_status(c);
+    c->stream = to;
+    return rc;
 }
 
 int rm_set_output(rm_ctx* c, void* device_rgba, size_t pitch_bytes) {
@@ -658,7 +674,7 @@ int rm_set_batch(rm_ctx* c, size_t frames, size_t rgba_frame_stride_bytes, size_
         (void)hipFree(c->sched);
         c->sched = sched; c->overflow_cap = overflow_cap; c->list_cap = list_cap;
         c->history = false; c->seq = 0; c->expected_done = 0;
-        c->trips_seen = 0; c->launches_unchecked = 0; c->unchecked_tiles = 0; c->trips_per_tile = 0; c->longest_tile = 0;
+        c->launches_unchecked = 0; c->last_tiles = 0; c->trips_per_tile = 0; c->longest_tile = 0;
     }
     if (c->out == c->fb) {               // a caller-owned output needs no planes of the context's own
         int rc = grow_framebuffer(c, frames);
@@ -769,8 +785,10 @@ int rm_process_static(rm_ctx* c, const rm_rays_info* info, void* device_rgba, si
     if (tiles > RM_STATIC_MAX_TILES) return RM_ERR_TOO_LARGE;        // the array holds lists for that many tiles, no more
     if (c->local_rows == 0) return RM_OK;
     HIP_TRY(hipSetDevice(c->device));
-    std::lock_guard<std::mutex> lock(g_static_mutex);
-    StaticSched& st = g_static[c->device];
+    StaticSched* found = nullptr;
+    { std::lock_guard<std::mutex> lock(g_static_mutex); found = &g_static[c->device]; }
+    StaticSched& st = *found;
+    std::lock_guard<std::mutex> lock(st.mu);                         // this device's block is ours until the frame is in
     if (!st.ptr) return RM_ERR_NOT_READY;                            // rm_create looked it up: cannot happen
     rm::RenderParams p;
     fill_params(c, p);
@@ -780,6 +798,7 @@ int rm_process_static(rm_ctx* c, const rm_rays_info* info, void* device_rgba, si
     camera_from(info, p.cams[0]);
     point_at_schedule(p, st.ptr, st.seq, RM_STATIC_LIST_CAP, RM_STATIC_MAX_TILES);
     p.ordered = (c->feedback && st.history && st.width == c->width && st.local_rows == c->local_rows) ? 1u : 0u;
+    p.hist_tiles = static_cast<uint32_t>(tiles);
     const bool jit = c->jit_active && c->evaluator == 0;
     const unsigned blocks = render_blocks(c, jit, 1);
     // The block keeps what the last call on this device left in it.  This launch's own counter set must
@@ -788,13 +807,27 @@ int rm_process_static(rm_ctx* c, const rm_rays_info* info, void* device_rgba, si
     HIP_TRY(hipMemsetAsync(p.set_cur, 0, RM_SET_DWORDS * sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(jit ? rm::jit_launch_render(c->jit, p, blocks, c->stream) : rm::launch_render(p, blocks, c->lds_bytes, c->stream));
+    // From here on a kernel is using the shared block: whatever fails below, the call does not return (and let
+    // the next call on this device in) before the stream has been waited for, and a failure leaves the block
+    // marked as holding nothing the next call may trust.
     ++st.seq;
     st.history = c->feedback; st.width = c->width; st.local_rows = c->local_rows;
     st.expected_done += static_cast<uint32_t>(tiles);
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->status_host, p.status, RM_STATUS_DWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (elapsed_ms) HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    hipError_t e = hipEventRecord(c->ev1, c->stream);
+    hipError_t e2 = hipMemcpyAsync(c->status_host, p.status, RM_STATUS_DWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = e2;
+    e2 = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = e2;
+    if (e == hipSuccess && elapsed_ms) e = hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1);
+    if (e != hipSuccess) {
+        // the status copy cannot be relied on: take the device's count as it stands for the next call to build on
+        st.history = false;
+        uint32_t done = 0;
+        if (hipMemcpy(c->status_host, p.status, RM_STATUS_DWORDS * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < RM_STATUS_COUNTERS; ++k) done += c->status_host[k * RM_STATUS_STRIDE];
+        st.expected_done = done;
+        return static_cast<int>(e);
+    }
     uint32_t done = 0;
     for (int k = 0; k < RM_STATUS_COUNTERS; ++k) done += c->status_host[k * RM_STATUS_STRIDE];
     if (done == st.expected_done && c->status_host[RM_STATUS_FLAG] == 0) return RM_OK;

@@ -111,14 +111,20 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
 
     // this frame found its scheduler set at zero; leave the next frame's at zero too
     if (blockIdx.x == 0 && threadIdx.x < RM_SET_LINES) prm.set_next[threadIdx.x * RM_QUEUE_STRIDE] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < RM_STATUS_COUNTERS)        // the longest-tile slot of the launch after this one
+    if (blockIdx.x == 0 && threadIdx.x < RM_STATUS_COUNTERS) {      // the trips and longest-tile slots of the launch after this one
+        prm.status[threadIdx.x * RM_STATUS_STRIDE + RM_STATUS_TRIPS + (prm.stat_slot ^ 1u)] = 0;
         prm.status[threadIdx.x * RM_STATUS_STRIDE + RM_STATUS_LONGEST + (prm.stat_slot ^ 1u)] = 0;
+    }
 
     const uint32_t tiles_x = (prm.width + 7) >> 3, tiles_y = (prm.local_rows + 7) >> 3;
     const uint32_t ntiles_frame = tiles_x * tiles_y;
     const uint32_t ntiles = ntiles_frame * prm.nframes;      // a launch of several frames (rm_set_batch) is one pool of tiles
     const uint32_t home = blockIdx.x & (RM_QUEUE_HEADS - 1);
     const bool ordered = prm.ordered != 0;
+    // a launch of more frames than the one before it: the lists hold the tiles of that one's frames, the rest
+    // (ids hist_tiles..ntiles) go out behind them in natural order, from a pseudo-head of their own
+    const uint32_t hist_tiles = ordered ? (prm.hist_tiles < ntiles ? prm.hist_tiles : ntiles) : ntiles;
+    const uint32_t last_cursor = ordered ? (hist_tiles < ntiles ? RM_QUEUE_HEADS + 1 : RM_QUEUE_HEADS) : RM_QUEUE_HEADS - 1;
 
     // ---- tile queue (wave-uniform; values that come from memory sit in a VGPR until they are needed)
     auto uniform = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
@@ -159,8 +165,13 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     uint32_t a_cum[RM_COST_BUCKETS];                                   // running list lengths of a_head
     bool a_done = false;
     auto open_head = [&]() {
-        a_head = a_cursor < RM_QUEUE_HEADS ? ((home + a_cursor) & (RM_QUEUE_HEADS - 1)) : RM_QUEUE_HEADS;
-        if (ordered) {
+        // (a_cursor RM_QUEUE_HEADS: the overflow list; RM_QUEUE_HEADS + 1: the tail of tiles the lists do not hold)
+        a_head = a_cursor < RM_QUEUE_HEADS ? ((home + a_cursor) & (RM_QUEUE_HEADS - 1)) : a_cursor;
+        if (ordered && a_head > RM_QUEUE_HEADS) {
+#pragma unroll
+            for (int b = 0; b < RM_COST_BUCKETS; ++b) a_cum[b] = 0;
+            a_total = ntiles - hist_tiles;
+        } else if (ordered) {
             uint32_t sum = 0;
             KernargParams* kp = kernarg_params();
             const uint32_t* set_prev = kp->set_prev;
@@ -196,7 +207,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         while (!a_done) {
             const uint32_t c = uniform(a_ticket) + a_pos;
             if (c < a_total) {
-                if (ordered) {
+                if (ordered && a_head > RM_QUEUE_HEADS) {
+                    s_val = hist_tiles + c;
+                    s_bucket = RM_COST_BUCKETS - 1;
+                } else if (ordered) {
                     uint32_t b = 0, base = 0;
 #pragma unroll
                     for (int k = 0; k + 1 < RM_COST_BUCKETS; ++k)
@@ -217,7 +231,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 return;
             }
             // this head is dry: on to the next one, the overflow list last (it exists only with history)
-            if (++a_cursor > (ordered ? RM_QUEUE_HEADS : RM_QUEUE_HEADS - 1)) { a_done = true; return; }
+            if (++a_cursor > last_cursor) { a_done = true; return; }
             open_head();
         }
     };
@@ -561,7 +575,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         uint32_t* line = status + (blockIdx.x & (RM_STATUS_COUNTERS - 1)) * RM_STATUS_STRIDE;
         if (tiles_done) {
             __hip_atomic_fetch_add(line, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(line + RM_STATUS_TRIPS, st_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(line + RM_STATUS_TRIPS + kernarg_params()->stat_slot, st_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_max(line + RM_STATUS_LONGEST + kernarg_params()->stat_slot, st_longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (expired) __hip_atomic_fetch_or(status + RM_STATUS_FLAG, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -13,7 +13,8 @@
 #define RM_COST_BUCKETS  8       // tiles are sorted by cost into this many lists per head
 #define RM_QUEUE_STRIDE  32      // dwords between counters: each on a 128-byte line of its own
 // One scheduler set = 96 counters (lines):
-//   [0..7]          pull position of head h;  [8] pull position of the overflow list
+//   [0..7]          pull position of head h;  [8] pull position of the overflow list;  [9] of the tail (tiles of
+//                   frames the previous launch did not have, in natural order)
 //   [16 + 8*h + b]  length of the list (head h, cost bucket b) written by the frame that owns the set
 //   [80]            length of the overflow list written by that frame
 #define RM_SET_PULL(h)     ((h) * RM_QUEUE_STRIDE)
@@ -48,11 +49,12 @@
 // words so that the end of a launch is not 8000 atomics on one), and a wavefront that leaves on the
 // watchdog sets the flag word behind them.  The host knows how many tiles it has launched.
 // Beside its tile count every line holds what the host sizes the next launch's grid from: the march-loop
-// trips of the line's wavefronts (running sum) and the trips of their longest tile (a maximum per launch: two
-// slots used in turn, a launch clears the one the next launch will use).
+// trips of the line's wavefronts and the trips of their longest tile, both per launch (two slots each, used
+// in turn: a launch clears the pair the next launch will use), so neither wraps however many launches go
+// unchecked (a launch of 2^22 tiles of 500 trips spreads 2^31 trips over 64 words).
 #define RM_STATUS_COUNTERS 64
-#define RM_STATUS_TRIPS    1       // dword of a line: trips, running sum
-#define RM_STATUS_LONGEST  2       // dwords 2, 3 of a line: longest tile of launch seq (slot seq & 1)
+#define RM_STATUS_TRIPS    1       // dwords 1, 2 of a line: trips of launch seq (slot seq & 1)
+#define RM_STATUS_LONGEST  3       // dwords 3, 4 of a line: longest tile of launch seq (slot seq & 1)
 #define RM_STATUS_STRIDE   16      // dwords between counters
 #define RM_STATUS_FLAG     (RM_STATUS_COUNTERS * RM_STATUS_STRIDE)
 #define RM_STATUS_DWORDS   ((RM_STATUS_COUNTERS + 1) * RM_STATUS_STRIDE)
@@ -119,6 +121,9 @@ struct RenderParams {
     uint32_t* lists_cur;          // the same for the next frame, written by this one
     uint32_t list_cap, overflow_cap;
     uint32_t ordered;             // 1: hand out lists_prev; 0: no history, natural tile order
+    // ordered: the lists hold the tile ids below hist_tiles (the previous launch's frames); a launch of more
+    // frames hands out the ids from there up in natural order, behind the lists (pull counter line 9 of the set)
+    uint32_t hist_tiles;
     uint32_t feedback;            // 1: write lists_cur
     uint32_t boost_age;           // loop trips after which a tile raises its wave's issue priority
     unsigned long long watchdog;  // shader clock ticks (s_memtime) after which a wavefront gives up (rm_debug_set_watchdog)

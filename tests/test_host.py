@@ -366,6 +366,37 @@ def test_a_launch_that_is_not_full_sets_no_batch(steps, batch, contexts, want):
     assert not [c for c in log if c[1] == "set_batch"]
 
 
+def test_timed_blocks_follow_each_other_without_a_wait():
+    """bench.py's measured part (batching.run_blocks): one untimed block and the timed ones are nothing but cameras,
+    launches and event marks - the fake context would record a synchronize, a set_batch or anything else - and
+    every block goes out in the same launches.  bench.py itself collects garbage and synchronises before it,
+    never inside it."""
+    from raytracing_amd.batching import FrameBatcher, run_blocks
+    log = []
+
+    class Ctx(_FakeContext):
+        def __getattr__(self, name):                    # any other call (synchronize, set_batch, read_pixels...) is recorded
+            return lambda *a: self.log.append((self.name, name, None))
+
+    ctxs = [Ctx(log, 0)]
+    run = FrameBatcher(ctxs, 16, after=lambda j, n: log.append((j, "launch_mark", n)))
+    info = np.zeros(1, dtype=api.INFO_DTYPE)
+    marks, nxt = run_blocks(run, lambda k: info, 20, 7, lambda: log.append(("all", "mark", None)) or len(log), first=100)
+    assert nxt == 100 + 8 * 20 and len(marks) == 8 and run.launches == 16
+    calls = [c for _, c, _ in log]
+    assert set(calls) == {"set_info_batch", "process_async", "launch_mark", "mark"}
+    per_block = " ".join(calls).split(" mark")[:-1]
+    assert len(per_block) == 8 and len({b.strip() for b in per_block}) == 1
+    assert [n for _, c, n in log if c == "set_info_batch"] == [10, 10] * 8
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        text = f.read()
+    a, b = text.index("    start = mark()"), text.index("    drain()", text.index("    start = mark()"))
+    timed = text[a:b]
+    for banned in ("synchronize", "gc.", "barrier", "drain", ".cpu()", "torch.zeros", "torch.empty"):
+        assert banned not in timed, banned
+    assert text.index("gc.collect()") < a and text.index("gc.disable()") < a
+
+
 def test_bench_sets_the_batch_once_before_timing():
     """bench.py itself: rm_set_batch is called ahead of the warm-up only (once per layout: whole frames, or the
     bands of a deal), and the oracle is imported only for the CPU baseline (the camera block comes from the

@@ -45,6 +45,42 @@ def test_static_entry_point_matches_rm_process(stock_scenes):
             rm.close()
 
 
+def test_static_entry_point_allocates_nothing(stock_scenes):
+    """The property the entry point exists for: between the device's free-memory readings (hipMemGetInfo) before
+    and after a run of calls - other cameras, a second context of another size and scene taking turns on the same
+    array - not a byte of device memory is taken or given back.  (The contexts and the output buffers exist
+    before the first reading; one warm call per context comes first, so that anything the runtime sets up lazily
+    for a first launch is not counted as the call's.)"""
+    torch = pytest.importorskip("torch")
+    shapes = [("chair", 640, 360), ("infinity", 333, 190)]
+    ctxs, bufs = [], []
+    try:
+        for name, w, h in shapes:
+            rm = api.Raymarching(w, h)
+            rm.set_nodes(stock_scenes[name])
+            ctxs.append(rm)
+            bufs.append(torch.zeros((h, w * 4), dtype=torch.uint8, device="cuda"))
+        infos = [O.default_info(1 + k, k) for k in range(6)]
+        for rm, buf in zip(ctxs, bufs):
+            rm.process_static(infos[0], buf.data_ptr(), buf.shape[1])
+        torch.cuda.synchronize()
+        free0, total = torch.cuda.mem_get_info()
+        for k, info in enumerate(infos):
+            j = k % len(ctxs)
+            ctxs[j].process_static(info, bufs[j].data_ptr(), bufs[j].shape[1])
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 == free0, "rm_process_static changed the device's free memory by %d bytes" % (free0 - free1)
+        # and what the last calls wrote is the frame
+        for j, (name, w, h) in enumerate(shapes):
+            k = max(i for i in range(len(infos)) if i % len(ctxs) == j)
+            ref = O.render(stock_scenes[name], w, h, infos[k], threads=min(16, os.cpu_count() or 4))
+            assert np.array_equal(bufs[j].cpu().numpy().reshape(h, w, 4), ref["rgba"])
+    finally:
+        for rm in ctxs:
+            rm.close()
+
+
 def test_static_entry_point_limits(stock_scenes):
     """Sizes beyond the array's 131 072 tiles are refused with RM_ERR_TOO_LARGE; bad arguments are errors."""
     torch = pytest.importorskip("torch")
