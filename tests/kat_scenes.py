@@ -235,3 +235,72 @@ def analytic_cases():
             d = np.sqrt(np.float32(float(d.split(":")[1])), dtype=np.float32)
         out.append((Tree(tree).table(), np.array(p, dtype=np.float32), np.float32(d), np.array(n, dtype=np.float32)))
     return out
+
+
+# Hand-derived WHOLE-PIXEL known answers: the march and shading loop of Source/cuda_kernels.cu:619-717 followed
+# step by step on paper, in scenes of planes (and one sphere on its axis) where every distance, every step and
+# every running sum is exact in fp32 or, where it is not (the shadow ray's travelled distance, which starts at
+# a = 2 * float(.02)), stays so far from every threshold it is compared with that its rounding cannot matter.
+# The camera block has StartWVec = StartHVec = 0, so every pixel of the frame is the same ray (:742-760:
+# pos = X*0 + Y*0, d = Depth*StartDir / |Depth*StartDir|, p = StartPos) and the whole frame must be the one
+# pixel worked out here.  (table, StartPos, StartDir, LightSource, RGBA, hit, primary root evaluations, shadow
+# root evaluations).  Shading constants used below: .9f - .1f rounds to 13421772 * 2^-24 (.79999995); with
+# N_L = SHADOW = 1 the luminance is 255 * float(.1f + .79999995f) = 255 * .9f = 229.49999 -> rounds to 229.5
+# -> LIGHT 229 -> (u8)(229*.5), (u8)(229*.7f), 229 = (114, 160, 229); with a zero product 255 * .1f = 25.5
+# -> LIGHT 25 -> (12, 17, 25).
+_FLOOR = ("ebeno", (0, 0, 1))                                       # DIST = z
+_WALL_X4 = ("movo", (4, 0, 0), ("ebeno", (-1, 0, 0)))               # DIST = 4 - x
+PIXELS = [
+    # A. A miss that leaves by ray_dist >= RAYS_MAX_DIST (:712).  Unit sphere, camera on its axis at z = 8 looking away:
+    #    p_k = 7*2^k + 1, cd_k = 7*2^k (sqrtf(z*z) == z), ray_dist after step k = 7*(2^(k+1) - 1) >= 1e4 first at k = 10:
+    #    11 evaluations, the black pixel of :622.
+    ("miss_by_distance", ("sfero", (1,)), (0, 0, 8), (0, 0, 1), (0, 0, 1), (0, 0, 0, 255), 0, 11, 0),
+    # B. A floor lit from straight above.  z = 8 -> cd 8 -> z = 0: cd = 0 < .02, not < -0.f: NORM = (0,0,1), R_1 = 1,
+    #    dot(n, d) = -1 < 0 (:640), N_L = 1.  Shadow ray from z = a = .04: cd = z doubles every step,
+    #    128*cd/ray_dist = 128 every time (SHADOW stays 1), ray_dist = a*2^(J+1) >= 1e4 first at J = 17 (:689): 18 evaluations.
+    ("lit_floor", _FLOOR, (0, 0, 8), (0, 0, -1), (0, 0, 1), (114, 160, 229, 255), 1, 2, 18),
+    # C. An occluded hit.  Floor z >= 0 and a wall x >= 4, light (1,0,1) (N_L = 1).  Primary: cd = min(8, 4) = 4, then
+    #    min(4, 4) = 4, then 0: kunigajo_2's normal takes child 0 because 0 < 4 (:153).  Shadow ray (a,0,a): cd = a*2^J
+    #    for J = 0..5 (floor nearer), at J = 6 the wall is nearer: cd = 4 - 64a, exact, and the step lands ON the wall:
+    #    x = z = ray_dist = 4 exactly.  J = 7: cd = 0, 8*0 < .02 (:662), the wall's normal (-1,0,0) against the VIEW
+    #    direction (quirk q4, :673): dot = 0 < .02 -> SHADOW = 0.
+    ("occluded", ("kunigajo_2", (), _FLOOR, _WALL_X4), (0, 0, 8), (0, 0, -1), (1, 0, 1), (12, 17, 25, 255), 1, 3, 8),
+    # D. A start inside a solid: the slab -1 < z < 0, camera at z = -63/64 looking down, light pointing down.
+    #    cd = max(z, -(z+1)) = -1/64 < -0.f (:630): the normal is -d = (0,0,1) although the nearest face's is (0,0,-1)
+    #    (with NORM the sample would face away and the ray would march on).  dot = -1: hit, N_L = -1 -> 0.  The shadow ray
+    #    starts below the slab (z = -(63/64 + a), rounded to 8593080 * 2^-23), cd = |z| - 1 = 204472 * 2^-23 doubles exactly,
+    #    128*cd/ray_dist >= 77 throughout, ray_dist = a + cd_0*(2^(J+1) - 1) >= 1e4 first at J = 18.  LIGHT = 255*(.1f + 0) = 25.5.
+    ("inside_start", ("komunajo_2", (), _FLOOR, ("komplemento", (), ("movo", (0, 0, -1), _FLOOR))),
+     (0, 0, -0.984375), (0, 0, -1), (0, 0, -1), (12, 17, 25, 255), 1, 1, 19),
+    # E. Near-surface samples that face away march on (quirk q1, :640 and :707-710).  Camera 1/64 above the floor moving
+    #    along +x: cd = 1/64 < .02 at every step, normal (0,0,1), dot(n, d) = 0 is not < 0: 128 steps of 1/64.  The wall
+    #    at x = 2 + 1/256 is farther than the floor until x = 2 (step 128): cd = 1/256, its normal (-1,0,0) faces the ray:
+    #    hit at the 129th evaluation, N_L = dot((-1,0,0), (-1,0,1)) = 1.  Shadow ray up and away from the wall: the wall
+    #    stays the nearer by 3145738 * 2^-28, cd doubles exactly from 368312 * 2^-23, SHADOW stays 1, ray_dist >= 1e4 at J = 17.
+    ("grazing_then_wall", ("kunigajo_2", (), _FLOOR, ("movo", (2.00390625, 0, 0), ("ebeno", (-1, 0, 0)))),
+     (0, 0, 0.015625), (1, 0, 0), (-1, 0, 1), (114, 160, 229, 255), 1, 129, 18),
+    # F. The shadow march's cap of 300 steps (:660) inside a penumbra.  Wall x >= 0 seen head-on from x = 8 at height 1/4 over
+    #    a floor: 32 primary steps of 1/4 (the floor is nearer), hit at x = 0 with the wall's normal, N_L = 1.  Shadow ray
+    #    back along +x: cd = a, 2a, 4a, then the floor's 1/4 for ever: SHADOW = min(SHADOW, 32/ray_dist) falls as ray_dist
+    #    = 8a + (J-3)/4 grows, never below .01 (:680), ray_dist never reaches 1e4: the loop ends at J = 300 with
+    #    SHADOW = 32/(8a + 74) = .430570 (ray_dist is rounded once per binade it crosses: < 1e-5 in all),
+    #    LIGHT = (u8)(255*(.1f + .79999995f*.430570)) = (u8)113.336 -> (56, 79, 113).  Without the cap: LIGHT 27.
+    ("shadow_step_cap", ("kunigajo_2", (), ("ebeno", (1, 0, 0)), _FLOOR),
+     (8, 0, 0.25), (-1, 0, 0), (1, 0, 0), (56, 79, 113, 255), 1, 33, 300),
+    # G. The primary march's cap of 500 steps (:626): E's camera without the wall.  500 near-surface samples that face away,
+    #    ray_dist = 500/64: the black pixel of a miss.
+    ("primary_step_cap", _FLOOR, (0, 0, 0.015625), (1, 0, 0), (0, 0, 1), (0, 0, 0, 255), 0, 500, 0),
+]
+
+
+def pixel_cases(info_dtype):
+    """[(name, table, rays_info block, rgba uint8[4], hit, primary evaluations, shadow evaluations)]"""
+    out = []
+    for name, tree, pos, direction, light, rgba, hit, n_primary, n_shadow in PIXELS:
+        info = np.zeros(1, dtype=info_dtype)
+        info["Depth"] = 1
+        for field, v in (("StartPos", pos), ("StartDir", direction), ("LightSource", light)):
+            for axis, x in zip("xyz", v):
+                info[field][axis] = x
+        out.append((name, Tree(tree).table(), info, np.array(rgba, dtype=np.uint8), hit, n_primary, n_shadow))
+    return out

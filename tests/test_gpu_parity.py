@@ -136,6 +136,30 @@ def test_hand_derived_known_answers():
                 assert same_floats(n[0], want_n), "%s: NORM %s, by hand %s" % (label, n[0], want_n)
 
 
+def test_hand_derived_whole_pixels():
+    """kat_scenes.PIXELS on the device: the march and shading loop (Source/cuda_kernels.cu:619-717) of every
+    kernel - generated code, compiled distance program, interpreter, tree walker - against pixels worked out on
+    paper, not against the oracle: a miss by distance, a lit floor, an occluded hit, a start inside a solid,
+    near-surface samples that march on, and both step caps.  With ray windows off the tiles' march-loop trips
+    must also be the root evaluations counted by hand (every lane of a tile is the same ray, so a tile makes
+    primary + shadow trips)."""
+    for name, table, info, rgba, hit, n_primary, n_shadow in kat_scenes.pixel_cases(api.INFO_DTYPE):
+        for path in sorted(PATHS):
+            got, mask, _ = gpu_render(table, 9, 9, info, path)
+            assert (got == rgba).all(), "%s on %s: pixel %s, by hand %s" % (name, path, got[4, 4], rgba)
+            assert (mask == hit).all(), "%s on %s: hit flag" % (name, path)
+        for jit in (2, 0):
+            with api.Raymarching(9, 9) as rm:
+                rm.set_jit(jit)
+                rm.set_ray_windows(False)
+                rm.set_nodes(table)
+                rm.set_info(info)
+                stats = rm.wave_stats()
+                assert int(stats[:, 6].sum()) == 4, "four tiles"
+                assert int(stats[:, 0].sum()) == 4 * (n_primary + n_shadow), (name, jit, int(stats[:, 0].sum()) / 4)
+                assert (rm.read_pixels() == rgba).all(), name
+
+
 def test_node_kat_inner_nodes():
     """The walker can start at any reachable node (sub-tree evaluation)."""
     table = kat_scenes.tables()["nested_frames"]

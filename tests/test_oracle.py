@@ -171,3 +171,17 @@ def test_hypot_convention():
         got = np.float32(O.dist(table, 0, (x, y, 0.0)))
         # exterior branch re-applies hypot to (max(q.x,0), max(q.y,0)) = (want, 0): still `want`
         assert got == want
+
+
+def test_hand_derived_whole_pixels():
+    """The march and shading loop (Source/cuda_kernels.cu:619-717) against answers worked out on paper
+    (kat_scenes.PIXELS): the pixel, the hit flag, and how many root evaluations each loop made - the only pin of
+    that loop beyond the survey's two frame hashes.  A 9x9 frame whose 81 rays are the same ray."""
+    import kat_scenes
+    for name, table, info, rgba, hit, n_primary, n_shadow in kat_scenes.pixel_cases(O.INFO_DTYPE):
+        r = O.render(table, 9, 9, info, want_evals=True, want_counters=True)
+        assert (r["rgba"] == rgba).all(), "%s: pixel %s, by hand %s" % (name, r["rgba"][4, 4], rgba)
+        assert (r["hit"] == hit).all(), name
+        assert r["counters"]["root_dist_primary"] == 81 * n_primary, (name, r["counters"]["root_dist_primary"] / 81)
+        assert r["counters"]["root_dist_shadow"] == 81 * n_shadow, (name, r["counters"]["root_dist_shadow"] / 81)
+        assert (r["evals"] == n_primary + n_shadow).all(), name
