@@ -187,6 +187,10 @@ def main():
     # check that the collective takes the tensors this path hands it.  The numbers it prints mean nothing.
     solo = world == 1 and os.environ.get("RM_BENCH_SOLO_GATHER", "0") == "1"
     multi = world > 1 or solo
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if not rehearsal and torch.cuda.device_count() < local_world:
+        raise SystemExit("bench.py: %d ranks on this node but only %d GPU(s) visible: one process per GPU (set "
+                         "RM_BENCH_REHEARSAL=1 to rehearse several ranks on one GPU over gloo)" % (local_world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if multi:
@@ -302,6 +306,8 @@ def main():
 
     host_times = [] if os.environ.get("RM_BENCH_HOST_TIMES") else None     # seconds of host time per after_launch
     launch_marks = None                                # set for the timed part
+    comm_marks = None                                  # N>1, the timed part: events around every launch's gather and rebuild
+    incomplete = []                                    # RM_ERR_INCOMPLETE met at a drain (reported, and the run exits non-zero)
 
     def after_launch(j, n):
         """N>1: the launch's luminance planes to rank 0 in one gather, RGBA8 frames rebuilt there."""
@@ -315,6 +321,9 @@ def main():
         rendered[j].record(streams[j])
         comm_stream.wait_event(rendered[j])
         with torch.cuda.stream(comm_stream):           # same order of gathers on every rank
+            if comm_marks is not None:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record(comm_stream)
             if not lay["gather"]:
                 pass                                   # the deal is being measured: render and rebuild only
             elif rehearsal:
@@ -326,8 +335,13 @@ def main():
                     lay["parts"][j][:, :n].copy_(torch.stack(got))
             else:
                 dist.gather(lay["bufs"][j][:n], list(lay["parts"][j][:, :n].unbind(0)) if rank == 0 else None, dst=0)     # the n frames of this launch only
+            if comm_marks is not None:
+                ev[1].record(comm_stream)
             if rank == 0:
                 rebuild(j, n)
+            if comm_marks is not None:
+                ev[2].record(comm_stream)
+                comm_marks.append(ev)
             gathered[j].record(comm_stream)
         if host_times is not None:
             host_times.append(time.perf_counter() - t_host)
@@ -341,7 +355,12 @@ def main():
     def drain():
         run.flush()                                    # frames that do not fill a launch
         for rm in ctxs:
-            rm.synchronize()                           # also the completeness check: raises on a frame with tiles missing
+            try:
+                rm.synchronize()                       # also the completeness check: a frame with tiles missing...
+            except api.RaymarchError as e:
+                if e.status != -10:                    # ...(RM_ERR_INCOMPLETE) is recorded, the ranks stay in step, and the
+                    raise                              # run ends with the ranks named and a non-zero exit code
+                incomplete.append(str(e))
         if multi:
             comm_stream.synchronize()
         torch.cuda.synchronize()
@@ -376,7 +395,8 @@ def main():
         best = max(range(len(shares)), key=lambda k: rates[k])
         weights = tiling.lighter_rank0(world, shares[best])
         lay_out(tiling.deal(weights))
-        deal_note = {"rank0_share_tried": list(shares), "slowest_rank_frames_per_s_without_gather": rates}
+        deal_note = {"rank0_share_tried": list(shares), "slowest_rank_frames_per_s_without_gather": rates,
+                     "this_rank_frames_per_s_without_gather": table}
 
     # Warm-up: at least --warmup frames, in whole launches, and at least --warmup-seconds of them: a fresh
     # box needs a few hundred milliseconds of work before its clocks are where a long run has them, and the
@@ -419,6 +439,7 @@ def main():
 
     timed_streams = list(streams) + ([comm_stream] if multi else [])
     launch_marks = [] if in_flight == 1 and not multi else None      # one stream: an event behind every launch
+    comm_marks = [] if multi else None
 
     def mark():
         evs = []
@@ -471,6 +492,25 @@ def main():
     elif rank == 0:
         frame = frames_out[run.last[1]]
 
+    # N>1: what every rank saw, so that the first run on a real 8-GPU node explains itself - the device each rank
+    # bound, its render-only rate for every candidate deal, the time its launches' gathers and rebuilds took on the
+    # communication stream (rank 0's gather is the ingest of all parts; another rank's is its send), and whether
+    # any of its launches came back incomplete
+    per_rank = None
+    if multi:
+        def med(v):
+            return sorted(v)[len(v) // 2] if v else None
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": torch.cuda.current_device(),
+                "device_name": props.name, "device_uuid": str(getattr(props, "uuid", "")),
+                "gather_ms_per_launch_median": med([e[0].elapsed_time(e[1]) for e in comm_marks]),
+                "gather_ms_per_launch_max": max([e[0].elapsed_time(e[1]) for e in comm_marks], default=None),
+                "rebuild_ms_per_launch_median": med([e[1].elapsed_time(e[2]) for e in comm_marks]) if rank == 0 else None,
+                "render_only_frames_per_s_by_rank0_share": (deal_note or {}).pop("this_rank_frames_per_s_without_gather", None),
+                "incomplete": incomplete}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank == 0:
         got = frame.cpu().numpy()
         hits = int(got[:, :, :3].any(-1).sum())
@@ -505,6 +545,12 @@ def main():
             "kernel_ms": kernel_ms, "launches": launches,
             **({"kernel_ms_per_launch": kernel_ms_all} if kernel_ms_all else {}),
         }
+        if multi:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["backend"] = dist.get_backend()
+            out["ranks"] = per_rank
+            out["incomplete_ranks"] = [r["rank"] for r in per_rank if r["incomplete"]]
+            out["distinct_devices"] = len({(r["device"], r["device_uuid"]) for r in per_rank})
         if want:
             # FLOPs of one launch (1/N of each of its frames), counted by the CPU restatement.
             # The kernel marches a primary ray only where it can be near the scene's volume (ray windows,
@@ -557,8 +603,12 @@ def main():
 
     for rm in ctxs:
         rm.close()
+    failed = bool(incomplete)
     if multi:
+        failed = any(r["incomplete"] for r in per_rank)
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: a launch came back RM_ERR_INCOMPLETE (tiles missing or a wavefront stopped by its watchdog)")
 
 
 if __name__ == "__main__":

@@ -203,6 +203,9 @@ int rm_synchronize(rm_ctx* ctx);
  * host memory, 17 GB/s into pageable memory on the MI355X box. */
 int rm_read_pixels(rm_ctx* ctx, void* host_rgba, size_t pitch_bytes);
 int rm_read_hit_mask(rm_ctx* ctx, void* host_mask, size_t pitch_bytes);
+/* rm_read_pixels for frame `frame` (< the rm_set_batch count) of the last launch: the plane that frame's camera
+ * block rendered into (no counterpart: the reference has one frame per Process(), Source/cuda_rays.cu:201-216). */
+int rm_read_pixels_of_frame(rm_ctx* ctx, size_t frame, void* host_rgba, size_t pitch_bytes);
 
 /* Device address and pitch of the buffer rm_process writes. */
 int rm_device_framebuffer(rm_ctx* ctx, void** device_rgba, size_t* pitch_bytes);

@@ -30,7 +30,7 @@ EXPORTS = [
     "rm_flatten_scene", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
     "rm_set_luminance_output", "rm_assemble_luminance", "rm_assemble_luminance_batch", "rm_set_batch", "rm_set_info_batch",
-    "rm_process_static", "rm_debug_set_watchdog", "rm_scene_bound_of", "rm_set_ray_windows",
+    "rm_process_static", "rm_debug_set_watchdog", "rm_scene_bound_of", "rm_set_ray_windows", "rm_read_pixels_of_frame",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
             "rm_synchronize": [vp],
             "rm_read_pixels": [vp, vp, sz],
             "rm_read_hit_mask": [vp, vp, sz],
+            "rm_read_pixels_of_frame": [vp, sz, vp, sz],
             "rm_device_framebuffer": [vp, C.POINTER(vp), C.POINTER(sz)],
             "rm_get_scene_stats": [vp, C.POINTER(SceneStats)],
             "rm_flatten_scene": [vp, sz, C.POINTER(SceneStats), C.c_char_p, sz],
@@ -349,6 +350,12 @@ class Raymarching:
         rows = self.local_rows()
         out = np.zeros((rows, self.width, 4), dtype=np.uint8)
         _check(lib().rm_read_pixels(self._ctx, _ptr(out), self.width * 4), "rm_read_pixels")
+        return out
+
+    def read_pixels_of_frame(self, frame):
+        """Frame `frame` of the last launch of several frames (rm_set_batch), from whichever planes it rendered into."""
+        out = np.zeros((self.local_rows(), self.width, 4), dtype=np.uint8)
+        _check(lib().rm_read_pixels_of_frame(self._ctx, frame, _ptr(out), self.width * 4), "rm_read_pixels_of_frame")
         return out
 
     def read_hit_mask(self):

@@ -861,6 +861,14 @@ int rm_read_pixels(rm_ctx* c, void* host_rgba, size_t pitch_bytes) {
     return read_rows(c, host_rgba, pitch_bytes, c->out, c->out_pitch, c->width * 4);
 }
 
+int rm_read_pixels_of_frame(rm_ctx* c, size_t frame, void* host_rgba, size_t pitch_bytes) {
+    if (!c || !host_rgba || pitch_bytes < c->width * 4 || frame >= c->batch) return RM_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->local_rows == 0) return RM_OK;
+    const size_t stride = c->out_frame_stride ? c->out_frame_stride : c->out_pitch * c->local_rows;
+    return read_rows(c, host_rgba, pitch_bytes, c->out + frame * stride, c->out_pitch, c->width * 4);
+}
+
 int rm_read_hit_mask(rm_ctx* c, void* host_mask, size_t pitch_bytes) {
     if (!c || !host_mask || pitch_bytes < c->width) return RM_ERR_INVALID_ARG;
     if (!c->hit) return RM_ERR_NOT_READY;

@@ -4,7 +4,12 @@
 // the place of the SDL window.
 //
 //   rm_render --width W --height H [--input scene.sce] [--frames K] [--drag-x PX] [--drag-y PX] [--script events.txt]
-//             [--out frame.ppm] [--device D] [--gpus N] [--devices D0,D1,...]
+//             [--out frame.ppm] [--device D] [--gpus N] [--devices D0,D1,...] [--frame-by-frame]
+//
+// The cameras of a run are known before its first frame (--frames K with a fixed drag per frame, or a script), so
+// the front end works the whole camera path out first and hands it to the backend in one call
+// (hip::raymarching::ProcessBatch: launches of several frames, rays.hpp); --frame-by-frame renders it as the
+// reference's loop does, one SetInfo and one Process() per frame (same pixels, 2x the time per frame).
 //
 // --gpus N: the frame is dealt to N GPUs in 8-row bands (hip::raymarching over several devices, rays.hpp; D,
 // D+1, ... unless --devices names them, and a device named twice gets two contexts); every frame is rendered by
@@ -56,6 +61,8 @@ int main(int argc, char** argv) {
     size_t Width = 0, Height = 0, Frames = 1;
     int DragX = 0, DragY = 0;          // scripted right-button drag per frame, pixels (Source/main.cpp:240-251)
     int Device = 0, Gpus = 1;
+    bool FrameByFrame = false;
+    for (int I = 1; I < argc; ++I) if (string(argv[I]) == "--frame-by-frame") FrameByFrame = true;
     string File, Out, Script, Devices;
 
     string arg;
@@ -146,6 +153,19 @@ int main(int argc, char** argv) {
 
     double kernel_ms = 0.0;
     auto t0 = chrono::steady_clock::now();
+    vector<rays_info> path;                                      // the camera blocks of the frames, in order
+    // one pass of the reference's loop body (Source/main.cpp:269-270): now, or collected for ProcessBatch
+    auto render = [&]() -> bool {
+        if (!FrameByFrame) { path.push_back(Info_h); return true; }
+        HIP->SetInfo(Info_h);
+        HIP->Process();
+        if (backend->LastStatus()) {
+            cerr << "\nProcess failed: " << backend->LastStatus() << " (" << rm_status_string(backend->LastStatus()) << ")" << endl;
+            return false;
+        }
+        kernel_ms += backend->ProcessTime();
+        return true;
+    };
     auto set_vectors = [&]() {                                   // Source/main.cpp:253-255
         Info_h.StartDir = point{ scale * cos_theta * cos_phi, scale * cos_theta * sin_phi, scale * sin_theta };
         Info_h.StartWVec = point{ scale * sin_phi, -scale * cos_phi, 0.f };
@@ -212,13 +232,7 @@ int main(int argc, char** argv) {
                         cos_1 * Info_h.LightSource.x - sin_1 * Info_h.LightSource.y,
                         sin_1 * Info_h.LightSource.x + cos_1 * Info_h.LightSource.y,
                         Info_h.LightSource.z };
-                HIP->SetInfo(Info_h);
-                HIP->Process();
-                if (backend->LastStatus()) {
-                    cerr << "Process failed: " << backend->LastStatus() << " (" << rm_status_string(backend->LastStatus()) << ")" << endl;
-                    return 1;
-                }
-                kernel_ms += backend->ProcessTime();
+                if (!render()) return 1;
                 ++Frames;
             } else {
                 cerr << Script << ": unknown event '" << what << "'" << endl;
@@ -249,16 +263,20 @@ int main(int argc, char** argv) {
             cos_1 * Info_h.LightSource.x - sin_1 * Info_h.LightSource.y,
             sin_1 * Info_h.LightSource.x + cos_1 * Info_h.LightSource.y,
             Info_h.LightSource.z };
-        HIP->SetInfo(Info_h);
-        size_t compute_time = HIP->Process();
+        if (!render()) return 1;
+        if (FrameByFrame) {
+            auto f1 = chrono::steady_clock::now();
+            cout << "\rFrame time : " << chrono::duration_cast<chrono::milliseconds>(f1 - f0).count()
+                 << "ms  \t\tTask execution time : " << size_t(backend->ProcessTime()) << "ms  " << flush;   // Source/main.cpp:287
+        }
+    }
+    if (!path.empty()) {
+        backend->ProcessBatch(path.data(), path.size());
         if (backend->LastStatus()) {
-            cerr << "\nProcess failed: " << backend->LastStatus() << " (" << rm_status_string(backend->LastStatus()) << ")" << endl;
+            cerr << "ProcessBatch failed: " << backend->LastStatus() << " (" << rm_status_string(backend->LastStatus()) << ")" << endl;
             return 1;
         }
-        kernel_ms += backend->ProcessTime();
-        auto f1 = chrono::steady_clock::now();
-        cout << "\rFrame time : " << chrono::duration_cast<chrono::milliseconds>(f1 - f0).count()
-             << "ms  \t\tTask execution time : " << compute_time << "ms  " << flush;   // Source/main.cpp:287
+        kernel_ms = backend->ProcessTime();
     }
     double secs = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
     cout << endl << Frames << " frame(s) " << Width << "x" << Height << " on " << backend->Gpus() << " GPU context(s): "

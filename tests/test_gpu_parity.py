@@ -529,6 +529,10 @@ def test_batch_of_frames_in_one_launch(stock_scenes):
                 rm.set_info_batch(infos[1:3])
                 rm.process()
                 assert np.array_equal(rm.read_pixels(), singles[1])
+                assert np.array_equal(rm.read_pixels_of_frame(0), singles[1])
+                assert np.array_equal(rm.read_pixels_of_frame(1), singles[2])
+                with pytest.raises(api.RaymarchError):
+                    rm.read_pixels_of_frame(2)
                 assert np.array_equal(rm.read_hit_mask(), masks[1])
                 with pytest.raises(api.RaymarchError):
                     rm.set_batch(33)
@@ -839,16 +843,19 @@ def test_front_end_several_gpu_contexts(gpus, height, stock_scenes, golden_dir, 
         assert f.read() == O.ppm_bytes(ref["rgba"])
 
 
-def test_front_end_scripted_sweep(stock_scenes, golden_dir, tmp_path):
+@pytest.mark.parametrize("frames,extra", [(70, []), (25, ["--frame-by-frame"])])
+def test_front_end_scripted_sweep(frames, extra, stock_scenes, golden_dir, tmp_path):
     """--frames K --drag-x 1 is config 5's camera path: the front end's own float
     maths (Source/main.cpp:240-266) must land on the committed rays_info of frame K-1, so the PPM of
-    the last frame equals the oracle's frame for that block."""
+    the last frame equals the oracle's frame for that block.  The camera path is known ahead, so the
+    front end hands it to hip::raymarching::ProcessBatch (70 frames: launches of 24, 23 and 23);
+    --frame-by-frame is the reference's loop, a SetInfo and a Process() per frame."""
     import subprocess
     sweep = np.fromfile(os.path.join(golden_dir, "sweep_rays_info.bin"), dtype=api.INFO_DTYPE)
     out = str(tmp_path / "sweep.ppm")
-    w, h, frames = 320, 180, 25
+    w, h = 320, 180
     run = subprocess.run([os.path.join(ROOT, "raytracing_amd", "rm_render"), "--width", str(w), "--height", str(h), "--input",
-                          os.path.join(golden_dir, "scenes", "chair.sce"), "--frames", str(frames), "--drag-x", "1", "--out", out],
+                          os.path.join(golden_dir, "scenes", "chair.sce"), "--frames", str(frames), "--drag-x", "1", "--out", out] + extra,
                          capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stderr + run.stdout
     ref = O.render(stock_scenes["chair"], w, h, sweep[frames - 1:frames], threads=min(16, os.cpu_count() or 4))
@@ -906,6 +913,15 @@ def test_bench_two_ranks_on_one_gpu(golden_dir):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 13 and rec["launches"] == 4
     assert rec["parity"]["frame_matches_golden"] is True
+    # what the first run on a real 8-GPU node will be read by: ranks, devices, per-rank rates, gather and rebuild times
+    assert rec["rccl_ranks"] == 2 and rec["backend"] == "gloo" and rec["incomplete_ranks"] == []
+    assert [r["rank"] for r in rec["ranks"]] == [0, 1] and rec["distinct_devices"] == 1       # (the rehearsal shares one GPU)
+    shares = rec["config"]["band_deal_measured"]["rank0_share_tried"]
+    for r in rec["ranks"]:
+        assert len(r["render_only_frames_per_s_by_rank0_share"]) == len(shares) and min(r["render_only_frames_per_s_by_rank0_share"]) > 0
+        assert r["gather_ms_per_launch_median"] > 0 and r["device_name"]
+    assert rec["ranks"][0]["rebuild_ms_per_launch_median"] > 0 and rec["ranks"][1]["rebuild_ms_per_launch_median"] is None
+    assert len(rec["config"]["band_weights"]) == 2 and len(rec["block_ms"]) == rec["repeats"] == 7
 
 
 def test_bench_gather_path_over_rccl_with_one_rank(golden_dir):
@@ -916,7 +932,12 @@ def test_bench_gather_path_over_rccl_with_one_rank(golden_dir):
     import json
     import subprocess
     import sys
-    env = dict(os.environ, RM_BENCH_SOLO_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RM_BENCH_SOLO_GATHER="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "13", "--warmup", "3",
@@ -925,5 +946,6 @@ def test_bench_gather_path_over_rccl_with_one_rank(golden_dir):
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["steps"] == 13 and rec["config"]["contexts_in_flight"] == 3
+    assert rec["rccl_ranks"] == 1 and rec["backend"] == "nccl" and rec["incomplete_ranks"] == []
     assert "row bands" in rec["config"]["partition"]
     assert rec["parity"]["frame_matches_golden"] is True
