@@ -306,6 +306,10 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // trip it is in a phase, every lane starts its primary march at trip 1 (so its step count is the
         // wave's trip count), and a lane that turns to the light at trip s has made J steps at trip s + J.
         uint32_t deadline = 0;                   // shadow lanes: the trip that is their step RM_SHADOW_STEPS
+        // ...and a trip no later than any shadow lane's deadline, wave-level (every lane that turns at trip s gets
+        // s + RM_SHADOW_STEPS): the per-lane compare (1.7 vector additions) is made by the general tail only, from that
+        // trip on, and the loop of the shadow-only trips runs up to it without one (stop_s, below)
+        uint32_t dl_min = 0xffffffffu;
         // what a shaded lane carries out of the loop: its luminance byte L (:694) under a flag bit; the pixel
         // is a function of L alone and is put together once, after the loop (one loop-carried value, not two)
         uint32_t shaded = 0;
@@ -327,6 +331,18 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         auto tier = [&](uint32_t k) { return k == 0 ? boost_age : k == 1 ? RM_PRIO_STEP2 * boost_age : RM_PRIO_STEP3 * boost_age; };
         uint32_t next_check = boost_age < 1023 ? boost_age + 1 : 1024;
         auto lanes = [](unsigned long long m) { return rm_lane_of_mask(m); };   // this lane's bit of a mask
+        // a compare as a lane mask that stays one: masks or-ed together in C++ are merged by the optimiser into one
+        // ballot of an or of booleans, which it then builds with a select and a second compare (3.4 vector additions)
+        auto mask_of = [](bool b) { unsigned long long m = __builtin_amdgcn_ballot_w64(b); asm("" : "+s"(m)); return m; };
+        // :662's `8 * cd < RAYS_MIN_DIST` without the product: scaling by 8 is exact in both directions (an overflowing
+        // 8 * cd is +-inf and compares as the huge cd does; NaN is false both ways), so the test is cd < RAYS_MIN_DIST / 8
+        constexpr float kShadowNear = RM_MIN_DIST * 0.125f;
+        static_assert(kShadowNear * 8.f == RM_MIN_DIST, "RM_MIN_DIST / 8 must be exact");
+        // shadow = min(shadow, (128*cd)/t) needs its division only where the quotient can be below `shadow`.  A shadow
+        // lane has shadow >= .01 and t >= .04, so st = RN(shadow*t) > 0 is normal; n_lo = RN(cd * 128(1 - 2^-21)) > st then
+        // gives 128*cd*(1 - 2^-21)(1 + 2^-24) > shadow*t*(1 - 2^-24), i.e. the exact quotient exceeds `shadow`, its
+        // rounding is >= shadow and min() keeps `shadow` bit for bit (a tiny or negative cd fails the test: division).
+        constexpr float kHardnessLow = RM_HARDNESS * (1.f - 0x1p-21f);
 
         // The scalar unit is shared by the four SIMDs of a CU and takes 4.3 cycles per instruction of a SIMD
         // (tools/microbench/valu_peak.hip, "mix"): a trip of ~70 vector instructions may hold ~35 scalar ones
@@ -336,6 +352,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // `due`: the trip at which the general tail must run whatever the lanes do (next_check; for primary
         // lanes also the step cap of :626).
         uint32_t due = next_check < (uint32_t)RM_PRIMARY_STEPS ? next_check : (uint32_t)RM_PRIMARY_STEPS;
+        uint32_t stop_s = next_check;            // shadow-only trips: min(next_check, dl_min)
         while (m_p | m_s) {
             P3 at;
             typename Scene::Keep keep;
@@ -366,27 +383,27 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     ++trips;
                     at = pos;
                     cd = scene.dist_keep(at, scratch, m_s, keep);             // :661
-                    if (__builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s) break;    // at a surface (:662)
+                    if (__builtin_amdgcn_ballot_w64(cd < kShadowNear) & m_s) break;        // at a surface (:662)
                     asm volatile("" ::: "memory");
-                    if (trips >= next_check) break;
+                    if (trips >= stop_s) break;
                     // shadow = min(shadow, (128*cd)/t), the division only in a trip in which it can lower some
                     // lane's shadow, and then for all of them (see the general tail)
-                    const float n = RM_HARDNESS * cd, st = shadow * t;
-                    if (__builtin_amdgcn_ballot_w64(!(n > __builtin_fmaf(fabsf(st), 4.8e-7f, st))) & m_s) {
+                    // (:680-690) the ends as compares straight into scalar masks (mask_of).  `shadow < .01` (:680) can
+                    // only become true where the quotient was taken: a marching lane's shadow was >= .01 before
+                    unsigned long long left = 0;
+                    if (__builtin_amdgcn_ballot_w64(!(cd * kHardnessLow > shadow * t)) & m_s) {
                         if (lanes(m_s)) {
-                            float ns = n;
+                            float ns = RM_HARDNESS * cd;
                             asm volatile("; shadow quotient" : "+v"(ns));       // keeps the division behind the branch
                             shadow = min2(shadow, ns / t);
                         }
+                        left = mask_of(shadow < 0.01f);
                     }
-                    // (:680-690) the three ends as three compares straight into scalar masks: a bool that is or-ed
-                    // together per lane costs a select and a compare more
-                    unsigned long long left = __builtin_amdgcn_ballot_w64(shadow < 0.01f);
                     if (lanes(m_s)) {
                         pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
                         t += cd;
                     }
-                    left = (left | __builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST) | __builtin_amdgcn_ballot_w64(trips >= deadline)) & m_s;
+                    left = (left | mask_of(t >= RM_MAX_DIST)) & m_s;       // (no lane is at its step cap before trip stop_s)
                     if (left) {                                                        // :693-701
                         if (lanes(left)) {
                             float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
@@ -422,7 +439,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 next_check = uniform(next_check); due = uniform(due);          // (the compiler would keep them in vector registers)
             }
             unsigned long long near = __builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST) & m_p;
-            if (m_s) near |= __builtin_amdgcn_ballot_w64(8 * cd < RM_MIN_DIST) & m_s;
+            if (m_s) near |= __builtin_amdgcn_ballot_w64(cd < kShadowNear) & m_s;
 
             // ---- rare: some lane is at a surface.  It takes its normal in this trip, at the point the distance
             // was just evaluated at: the normal's transforms and child distances are the ones computed above
@@ -455,6 +472,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     }
                 }
                 turn = __builtin_amdgcn_ballot_w64(turns);
+                if (turn && trips + RM_SHADOW_STEPS < dl_min) dl_min = trips + RM_SHADOW_STEPS;
                 occluded = __builtin_amdgcn_ballot_w64(hidden);
                 if (prm.wave_stats) st_norm_cycles += (uint32_t)(__builtin_amdgcn_s_memtime() - st_n0);
             }
@@ -480,23 +498,28 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 // `shadow` bit for bit.  The division (12 instructions) runs only in a trip in which some
                 // shadow lane needs it, and then for all of them (for the others min() changes nothing):
                 // one scalar branch, no divergence.
-                const float n = RM_HARDNESS * cd, st = shadow * t;
-                if (__builtin_amdgcn_ballot_w64(!(n > __builtin_fmaf(fabsf(st), 4.8e-7f, st))) & go_s) {
+                if (__builtin_amdgcn_ballot_w64(!(cd * kHardnessLow > shadow * t)) & go_s) {
                     if (lanes(go_s)) {
-                        float ns = n;
+                        float ns = RM_HARDNESS * cd;
                         asm volatile("; shadow quotient" : "+v"(ns));           // keeps the division behind the branch
                         shadow = min2(shadow, ns / t);
                     }
+                    left_s = mask_of(shadow < 0.01f);        // (only a quotient can bring a marching lane's shadow below .01)
                 }
                 // (:680-690) a lane whose shadow fell below .01 stops before the step, one that marches past
                 // RM_MAX_DIST or has made RM_SHADOW_STEPS steps after it: either way it is shaded now and its
                 // position is dead, so every shadow lane takes the step and the three ends are one mask
-                left_s = __builtin_amdgcn_ballot_w64(shadow < 0.01f);
                 if (lanes(go_s)) {
                     pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
                     t += cd;
                 }
-                left_s = (left_s | __builtin_amdgcn_ballot_w64(t >= RM_MAX_DIST) | __builtin_amdgcn_ballot_w64(trips >= deadline)) & go_s;
+                left_s |= mask_of(t >= RM_MAX_DIST);
+                if (trips >= dl_min) {
+                    left_s |= mask_of(trips >= deadline);
+                    // nobody due within 16 trips: look again then; else at every trip (through this tail) until they are
+                    dl_min = (mask_of(deadline <= trips + 16) & go_s) ? trips + 1 : trips + 17;
+                }
+                left_s &= go_s;
             }
 
             // ---- lanes whose shadow march ended are shaded (:693-701)
@@ -509,6 +532,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             }
             m_p = go_p & ~left_p;
             m_s = (go_s & ~left_s) | turn;
+            stop_s = next_check < dl_min ? next_check : dl_min;
         }
         st_evals += trips;
         st_longest = trips > st_longest ? trips : st_longest;
