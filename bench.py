@@ -360,7 +360,7 @@ def main():
             except api.RaymarchError as e:
                 if e.status != -10:                    # ...(RM_ERR_INCOMPLETE) is recorded, the ranks stay in step, and the
                     raise                              # run ends with the ranks named and a non-zero exit code
-                incomplete.append(str(e))
+                incomplete.append("%s: tiles finished %d, launched %d, watchdog flag %d" % ((str(e),) + rm.last_check()))
         if multi:
             comm_stream.synchronize()
         torch.cuda.synchronize()

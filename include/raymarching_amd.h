@@ -312,8 +312,16 @@ int rm_set_evaluator(rm_ctx* ctx, int which);
  * With host_out NULL only *n_waves is set. */
 int rm_debug_wave_stats(rm_ctx* ctx, uint32_t* host_out, size_t cap_waves, size_t* n_waves);
 
-/* Diagnostics: the persistent wavefronts' watchdog, in s_memtime ticks (0 restores
- * the default, 2^36).  A wavefront that has been in the kernel for longer gives up
+/* Diagnostics: what the last completion check of the context compared (rm_process,
+ * rm_synchronize, rm_read_*, rm_set_stream): tiles the wavefronts reported finished
+ * and tiles launched, both modulo 2^32 since the context was made, and the flag a
+ * wavefront sets when its watchdog stops it.  After RM_ERR_INCOMPLETE it tells a
+ * missing tile (counts differ) from a stopped wavefront (flag set). */
+int rm_debug_last_check(rm_ctx* ctx, unsigned* tiles_done, unsigned* tiles_expected, unsigned* watchdog_flag);
+
+/* Diagnostics: the persistent wavefronts' watchdog, in ticks of the 100 MHz clock all
+ * XCDs share (s_memrealtime; 0 restores the default, 2^36: eleven minutes).  A wavefront
+ * that has been in the kernel for longer gives up
  * at its next look at the clock (every 1024 march-loop trips, and where a tile's
  * priority steps up: rm_set_boost_age) and the launch is reported as
  * RM_ERR_INCOMPLETE.  Tests lower it to see that error path work. */

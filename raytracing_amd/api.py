@@ -30,7 +30,7 @@ EXPORTS = [
     "rm_flatten_scene", "rm_set_evaluator", "rm_status_string",
     "rm_eval_points", "rm_eval_rays", "rm_debug_wave_stats", "rm_set_boost_age", "rm_set_heavy_first", "rm_selftest_math", "rm_set_short_math", "rm_set_culling", "rm_set_jit", "rm_jit_log", "rm_jit_check",
     "rm_set_luminance_output", "rm_assemble_luminance", "rm_assemble_luminance_batch", "rm_set_batch", "rm_set_info_batch",
-    "rm_process_static", "rm_debug_set_watchdog", "rm_scene_bound_of", "rm_set_ray_windows", "rm_read_pixels_of_frame",
+    "rm_process_static", "rm_debug_set_watchdog", "rm_scene_bound_of", "rm_set_ray_windows", "rm_read_pixels_of_frame", "rm_debug_last_check",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
             "rm_set_evaluator": [vp, i32],
             "rm_set_boost_age": [vp, C.c_uint],
             "rm_debug_set_watchdog": [vp, C.c_ulonglong],
+            "rm_debug_last_check": [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)],
             "rm_set_heavy_first": [vp, i32],
             "rm_selftest_math": [vp, vp, sz, C.POINTER(C.c_ulonglong), vp],
             "rm_set_short_math": [vp, i32],
@@ -317,6 +318,12 @@ class Raymarching:
 
     def set_watchdog(self, ticks):
         _check(lib().rm_debug_set_watchdog(self._ctx, ticks), "rm_debug_set_watchdog")
+
+    def last_check(self):
+        """(tiles reported finished, tiles launched, watchdog flag) of the context's last completion check."""
+        d, e, f = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+        _check(lib().rm_debug_last_check(self._ctx, C.byref(d), C.byref(e), C.byref(f)), "rm_debug_last_check")
+        return d.value, e.value, f.value
 
     def set_evaluator(self, which):
         _check(lib().rm_set_evaluator(self._ctx, which), "rm_set_evaluator")

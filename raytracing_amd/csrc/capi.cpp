@@ -70,6 +70,7 @@ struct rm_ctx {
     // wavefronts report finished, both modulo 2^32
     uint32_t* status_host = nullptr;  // pinned copy of the device's status block
     uint32_t expected_done = 0;
+    uint32_t check_done = 0, check_expected = 0, check_flag = 0;   // what the last completion check compared (rm_debug_last_check)
     // what the last checked launches measured (judge_status), for the next launch's grid (render_blocks)
     uint32_t launches_unchecked = 0;  // launches since the last check
     size_t last_tiles = 0;            // tiles of the last launch
@@ -278,6 +279,7 @@ int judge_status(rm_ctx* c) {
         c->longest_tile = longest;
         c->launches_unchecked = 0;
     }
+    c->check_done = done; c->check_expected = c->expected_done; c->check_flag = c->status_host[RM_STATUS_FLAG];
     if (done == c->expected_done && c->status_host[RM_STATUS_FLAG] == 0) return RM_OK;
     c->trips_per_tile = 0; c->longest_tile = 0;
     c->expected_done = done;
@@ -1039,6 +1041,14 @@ int rm_set_short_math(rm_ctx* c, int enable) {
 int rm_set_boost_age(rm_ctx* c, unsigned trips) {
     if (!c) return RM_ERR_INVALID_ARG;
     c->boost_age = trips;
+    return RM_OK;
+}
+
+int rm_debug_last_check(rm_ctx* c, unsigned* tiles_done, unsigned* tiles_expected, unsigned* watchdog_flag) {
+    if (!c) return RM_ERR_INVALID_ARG;
+    if (tiles_done) *tiles_done = c->check_done;
+    if (tiles_expected) *tiles_expected = c->check_expected;
+    if (watchdog_flag) *watchdog_flag = c->check_flag;
     return RM_OK;
 }
 

@@ -101,9 +101,29 @@ __device__ __forceinline__ float kubo_dist(P3 p, float bx, float by, float bz) {
     // in the sign of a zero result (and for NaN, which finite positions never produce).  The clamps
     // are squared, which drops the sign.  `inside` is used only where all three are negative: no
     // zero among them, and "all three negative" is "their maximum is negative" (-0 is not).
-    float inside = __builtin_fmaxf(__builtin_fmaxf(qx, qy), qz);
-    float outside = length_3(__builtin_fmaxf(qx, 0.f), __builtin_fmaxf(qy, 0.f), __builtin_fmaxf(qz, 0.f));
-    return inside < 0.f ? inside : outside;
+    // The range test of the short square root (sqrt_exact) is the inside test as well: a sum of the squared
+    // clamps of at least 2^-102 has a positive clamp in it, so the point is not inside and the value is the
+    // exterior one (:92); a wave with a lane inside the box (sum 0), or with a sum that small, infinite or NaN,
+    // takes the branch, which is the reference's selection as it stands (:86-92).  Off the box that is the
+    // maximum, a compare and a select less per evaluation (each costs 1.7 vector additions on this chip).
+    const float cx = __builtin_fmaxf(qx, 0.f), cy = __builtin_fmaxf(qy, 0.f), cz = __builtin_fmaxf(qz, 0.f);
+    const float s = cx * cx + cy * cy + cz * cz;
+    const float r = __builtin_amdgcn_rsqf(s);
+    const float g = s * r, h = 0.5f * r;
+    float y = __builtin_fmaf(__builtin_fmaf(-g, g, s), h, g);
+    const bool odd = as_u(s) - 0x0d800000u >= 0x72000000u;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {               // rare off the box, whole wave
+        float ss = s;
+        asm volatile("; kubo_dist: inside the box, or IEEE path" : "+v"(ss));       // keeps this a branch
+        const float inside = __builtin_fmaxf(__builtin_fmaxf(qx, qy), qz);
+        const bool in = inside < 0.f;
+        if (__builtin_amdgcn_ballot_w64(odd && !in) != 0) {                        // on the surface (sqrt 0), or out of the short range
+            const float e = sqrtf(ss);
+            y = odd ? e : y;
+        }
+        y = in ? inside : y;
+    }
+    return y;
 }
 
 __device__ __forceinline__ float cilindro_dist(P3 p, float r, float h) {

@@ -245,11 +245,14 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     const uint64_t st_t0 = prm.wave_stats ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t st_r0 = prm.wave_stats ? __builtin_amdgcn_s_memrealtime() : 0;        // the 100 MHz clock all XCDs share
 
-    // Safety net for the persistent loop: every wave leaves after prm.watchdog clock ticks (2^36, about
-    // ten minutes of s_memtime, unless a test lowered it) whatever state it is in, so a defect in the
+    // Safety net for the persistent loop: every wave leaves after prm.watchdog ticks of the 100 MHz clock that
+    // all XCDs share (s_memrealtime; 2^36 ticks are eleven minutes, unless a test lowered it), compared as a signed
+    // difference.  (Until round 3 it read s_memtime, the shader-cycle counter: that one belongs to an XCD, and a
+    // wavefront that is preempted - two processes sharing the GPU - may resume where the counter reads less than
+    // it did at t_enter; the unsigned difference then looked like an expired watchdog.)  Whatever state it is in, so a defect in the
     // queue logic cannot hang the device.  It leaves a flag behind: the host reports the launch as
     // incomplete (RM_ERR_INCOMPLETE) instead of passing its frames on.
-    const uint64_t t_enter = __builtin_amdgcn_s_memtime();
+    const uint64_t t_enter = __builtin_amdgcn_s_memrealtime();
     bool expired = false;
 
     while (s_valid && !expired) {
@@ -431,7 +434,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     else if (level == 2) __builtin_amdgcn_s_setprio(2);
                     else __builtin_amdgcn_s_setprio(3);
                 }
-                if (__builtin_amdgcn_s_memtime() - t_enter > kernarg_params()->watchdog) { expired = true; break; }
+                if ((long long)(__builtin_amdgcn_s_memrealtime() - t_enter) > (long long)kernarg_params()->watchdog) { expired = true; break; }
                 next_check = trips + 1024;
                 if (boost_on && level < RM_PRIO_LEVELS && tier(level) >= trips && tier(level) - trips < 1024) next_check = tier(level) + 1;
                 due = next_check < (uint32_t)RM_PRIMARY_STEPS ? next_check : (uint32_t)RM_PRIMARY_STEPS;

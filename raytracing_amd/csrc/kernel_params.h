@@ -126,7 +126,7 @@ struct RenderParams {
     uint32_t hist_tiles;
     uint32_t feedback;            // 1: write lists_cur
     uint32_t boost_age;           // loop trips after which a tile raises its wave's issue priority
-    unsigned long long watchdog;  // shader clock ticks (s_memtime) after which a wavefront gives up (rm_debug_set_watchdog)
+    unsigned long long watchdog;  // ticks of the 100 MHz clock (s_memrealtime) after which a wavefront gives up (rm_debug_set_watchdog)
     // ray windows (device_render.h ray_window; rm_types.h): the scene's volume, its radius grown by the margin;
     // kind RM_BOUND_NONE when the scene offers none or windows are switched off
     uint32_t bound_kind;

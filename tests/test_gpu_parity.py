@@ -620,6 +620,8 @@ def test_incomplete_frame_is_reported(stock_scenes):
             with pytest.raises(api.RaymarchError) as e:
                 rm.process()
             assert e.value.status == -10
+            done, launched, flag = rm.last_check()       # what the check saw: fewer tiles than launched, the watchdog's flag
+            assert flag == 1 and done != launched
             rm.process_async()
             with pytest.raises(api.RaymarchError) as e:
                 rm.synchronize()
