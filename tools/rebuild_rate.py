@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracing_amd import api, tiling
 
-for w, h in ((3840, 2160), (7680, 4320)):
+sizes = ((3840, 2160), (7680, 4320)) if len(sys.argv) < 3 else ((int(sys.argv[1]), int(sys.argv[2])),)     # rebuild_rate.py [W H]
+for w, h in sizes:
     nranks, band, n = 8, 16, 32
     for weights in ([1] * 8, [3] + [5] * 7):
         owner = tiling.deal(weights)
