@@ -196,6 +196,15 @@ void fill_params(const rm_ctx* c, rm::RenderParams& p) {
     // order behind the lists (hist_tiles: the ids the lists hold)
     p.ordered = (c->feedback && c->history) ? 1u : 0u;
     p.hist_tiles = static_cast<uint32_t>(local_tiles(c) * std::min(c->nframes, c->history_frames));
+    // ...or, when it holds a whole multiple of them, every entry stands for the same tile of the frames further on
+    // too (list_reps): the frames of a camera path cost nearly the same tile by tile, so one frame's order serves a
+    // launch of sixteen (hip::raymarching::ProcessBatch starts a path with a launch of one frame for that)
+    p.list_reps = 1; p.list_reps_magic = 0;
+    if (p.ordered && c->history_frames > 0 && c->nframes > c->history_frames && c->nframes % c->history_frames == 0) {
+        const size_t reps = c->nframes / c->history_frames;
+        p.list_reps = static_cast<uint32_t>(reps);
+        p.list_reps_magic = static_cast<uint32_t>((uint64_t{1} << 32) / reps);       // reps >= 2
+    }
 }
 
 size_t sched_bytes(const rm_ctx* c) { return sched_dwords(c->list_cap, c->overflow_cap) * sizeof(uint32_t); }
@@ -801,6 +810,7 @@ int rm_process_static(rm_ctx* c, const rm_rays_info* info, void* device_rgba, si
     point_at_schedule(p, st.ptr, st.seq, RM_STATIC_LIST_CAP, RM_STATIC_MAX_TILES);
     p.ordered = (c->feedback && st.history && st.width == c->width && st.local_rows == c->local_rows) ? 1u : 0u;
     p.hist_tiles = static_cast<uint32_t>(tiles);
+    p.list_reps = 1; p.list_reps_magic = 0;
     const bool jit = c->jit_active && c->evaluator == 0;
     const unsigned blocks = render_blocks(c, jit, 1);
     // The block keeps what the last call on this device left in it.  This launch's own counter set must

@@ -124,7 +124,8 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // a launch of more frames than the one before it: the lists hold the tiles of that one's frames, the rest
     // (ids hist_tiles..ntiles) go out behind them in natural order, from a pseudo-head of their own
     const uint32_t hist_tiles = ordered ? (prm.hist_tiles < ntiles ? prm.hist_tiles : ntiles) : ntiles;
-    const uint32_t last_cursor = ordered ? (hist_tiles < ntiles ? RM_QUEUE_HEADS + 1 : RM_QUEUE_HEADS) : RM_QUEUE_HEADS - 1;
+    // (with list_reps > 1 the lists stand for every tile of the launch: no tail)
+    const uint32_t last_cursor = ordered ? ((hist_tiles < ntiles && prm.list_reps <= 1) ? RM_QUEUE_HEADS + 1 : RM_QUEUE_HEADS) : RM_QUEUE_HEADS - 1;
 
     // ---- tile queue (wave-uniform; values that come from memory sit in a VGPR until they are needed)
     auto uniform = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
@@ -175,13 +176,13 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             uint32_t sum = 0;
             KernargParams* kp = kernarg_params();
             const uint32_t* set_prev = kp->set_prev;
-            const uint32_t list_cap = kp->list_cap, overflow_cap = kp->overflow_cap;
+            const uint32_t list_cap = kp->list_cap, overflow_cap = kp->overflow_cap, reps = kp->list_reps;
 #pragma unroll
             for (int b = 0; b < RM_COST_BUCKETS; ++b) {
                 uint32_t n = 0;
                 if (a_head < RM_QUEUE_HEADS) n = min(set_prev[RM_SET_COUNT(a_head, b)], list_cap);
                 else if (b == 0)             n = min(set_prev[RM_SET_OVERFLOW], overflow_cap);
-                sum += n;
+                sum += n * reps;             // places: every entry list_reps times
                 a_cum[b] = sum;
             }
             a_total = sum;
@@ -217,7 +218,18 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                         if (c >= a_cum[k]) { b = k + 1; base = a_cum[k]; }
                     KernargParams* kp = kernarg_params();
                     const uint32_t* list = kp->lists_prev + (size_t)(a_head * RM_COST_BUCKETS + b) * kp->list_cap;
-                    s_val = __builtin_nontemporal_load(list + (c - base));
+                    const uint32_t reps = kp->list_reps;
+                    uint32_t at = c - base, rep = 0;
+                    if (reps > 1) {              // place -> (entry, which of the tiles it stands for): at / reps, at % reps
+                        uint32_t q = (uint32_t)(((unsigned long long)at * kp->list_reps_magic) >> 32);      // floor or one less
+                        rep = at - q * reps;
+                        if (rep >= reps) { ++q; rep -= reps; }
+                        at = q;
+                    }
+                    uint32_t entry = __builtin_nontemporal_load(list + at);
+                    // (an unfilled place reads 0xffffffff and must stay out of range whatever is added to it)
+                    if (reps > 1) entry = entry < hist_tiles ? entry + rep * hist_tiles : 0xffffffffu;
+                    s_val = entry;
                     s_bucket = a_head < RM_QUEUE_HEADS ? b : RM_COST_BUCKETS - 1;
                 } else {
                     s_val = a_head + RM_QUEUE_HEADS * c;

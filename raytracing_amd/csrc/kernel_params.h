@@ -124,6 +124,11 @@ struct RenderParams {
     // ordered: the lists hold the tile ids below hist_tiles (the previous launch's frames); a launch of more
     // frames hands out the ids from there up in natural order, behind the lists (pull counter line 9 of the set)
     uint32_t hist_tiles;
+    // ...unless its frame count is a multiple of the previous launch's: then every list entry stands for list_reps
+    // tiles, itself and the same tile of the frames hist_tiles, 2 hist_tiles, ... further on (consecutive frames of a
+    // camera path cost nearly the same tile by tile), handed out one after the other; list_reps_magic = floor(2^32 /
+    // list_reps) for the division (1 and 0: entries stand for themselves)
+    uint32_t list_reps, list_reps_magic;
     uint32_t feedback;            // 1: write lists_cur
     uint32_t boost_age;           // loop trips after which a tile raises its wave's issue priority
     unsigned long long watchdog;  // ticks of the 100 MHz clock (s_memrealtime) after which a wavefront gives up (rm_debug_set_watchdog)

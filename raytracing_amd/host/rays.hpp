@@ -229,12 +229,16 @@ public:
     int ProcessBatch(const rays_info* infos, size_t n) {
         if (ctx_.empty()) { last_ = RM_ERR_NOT_READY; return 0; }
         if (!infos || n == 0) { last_ = RM_ERR_INVALID_ARG; return 0; }
-        // launches of nearly equal size, the larger ones first (a launch of more frames than the one before it
-        // finds the extra frames' tiles in no list), of at most 2^23 tiles per context: more gain nothing
+        // A launch of ONE frame first: it learns in what order the tiles of this camera path should go out (the
+        // costliest first) and how many wavefronts a launch needs, and a launch of F frames behind a launch of one
+        // takes that order for each of its frames (raymarching_amd.h, rm_set_batch).  Then launches of nearly equal
+        // size, the larger ones first (a launch of more frames than the one before it, and not a multiple, finds the
+        // extra frames' tiles in no list), of at most 2^23 tiles per context: more gain nothing.
         const size_t tiles = ((Width + 7) / 8) * ((Height + 7) / 8) / ctx_.size() + 1;
         size_t cap = (size_t(1) << 23) / tiles;
         cap = cap < 1 ? 1 : cap > RM_MAX_BATCH ? RM_MAX_BATCH : cap;
-        const size_t launches = (n + cap - 1) / cap, small = n / launches, larger = n % launches;
+        const size_t lead = (cap > 1 && n > 2) ? 1 : 0, rest = n - lead;
+        const size_t launches = lead + (rest + cap - 1) / cap, small = rest / (launches - lead), larger = rest % (launches - lead);
         const size_t need = small + (larger ? 1 : 0);
         if (need > batch_) {                          // room is only ever added (rm_set_batch waits and may allocate)
             for (rm_ctx* c : ctx_) if ((last_ = rm_set_batch(c, need, 0, 0)) != RM_OK) return 0;
@@ -243,7 +247,7 @@ public:
         last_ms_ = 0.f;
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t k = 0, first = 0; k < launches; ++k) {
-            const size_t take = small + (k < larger ? 1 : 0);
+            const size_t take = (lead && k == 0) ? 1 : small + (k - lead < larger ? 1 : 0);
             for (rm_ctx* c : ctx_) if ((last_ = rm_set_info_batch(c, infos + first, take)) != RM_OK) return 0;
             if (ctx_.size() == 1) {
                 float ms = 0.f;

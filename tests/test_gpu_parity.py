@@ -562,9 +562,11 @@ def test_scene_every_ray_leaves_after_one_step():
 
 def test_launches_that_are_not_full(stock_scenes):
     """rm_set_info_batch(n) with n below the batch renders n frames and touches nothing else: launches of
-    5, 2, 5, 1, 3 frames on one context (so each runs on the tile order of a launch of another length;
-    where the one before was shorter the tiles of the extra frames are in no list and go out behind the
-    lists in natural order), every frame against the frames rendered one by one;
+    5, 2, 5, 1, 3, 1, 5, 2, 4, 1, 4 frames on one context, so each runs on the tile order of a launch of another
+    length: a longer one (entries of frames it does not have are skipped), a shorter one of which it is no
+    multiple (2 -> 5: the tiles of the extra frames are in no list and go out behind the lists in natural
+    order) or a shorter one of which it is (1 -> 3, 1 -> 5, 2 -> 4, 1 -> 4: every list entry stands for the same
+    tile of the frames further on as well); every frame against the frames rendered one by one;
     the planes of the frames a launch does not render keep what they held."""
     torch = pytest.importorskip("torch")
     w, h, cap = 200, 120, 5
@@ -584,7 +586,7 @@ def test_launches_that_are_not_full(stock_scenes):
             rm.set_nodes(nodes)
             rm.set_output(out.data_ptr(), w * 4)
             rm.set_batch(cap, h * w * 4, 0)
-            for n in (5, 2, 5, 1, 3):
+            for n in (5, 2, 5, 1, 3, 1, 5, 2, 4, 1, 4):
                 out.fill_(0x5a)
                 order = list(range(cap))[-n:] + list(range(cap))[:-n]          # another camera per slot each time
                 rm.set_info_batch(infos[order[:n]])
