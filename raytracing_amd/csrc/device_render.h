@@ -264,7 +264,14 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
     // it did at t_enter; the unsigned difference then looked like an expired watchdog.)  Whatever state it is in, so a defect in the
     // queue logic cannot hang the device.  It leaves a flag behind: the host reports the launch as
     // incomplete (RM_ERR_INCOMPLETE) instead of passing its frames on.
+#ifndef RM_WATCHDOG_SHADER_CLOCK          // 1: the clock and the unsigned compare of rounds 1-2, to reproduce what they did
+#define RM_WATCHDOG_SHADER_CLOCK 0       // (tools/two_process_stress.py, through RM_JIT_FLAGS); never in the product
+#endif
+#if RM_WATCHDOG_SHADER_CLOCK
+    const uint64_t t_enter = __builtin_amdgcn_s_memtime();
+#else
     const uint64_t t_enter = __builtin_amdgcn_s_memrealtime();
+#endif
     bool expired = false;
 
     while (s_valid && !expired) {
@@ -446,7 +453,11 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     else if (level == 2) __builtin_amdgcn_s_setprio(2);
                     else __builtin_amdgcn_s_setprio(3);
                 }
+#if RM_WATCHDOG_SHADER_CLOCK
+                if (__builtin_amdgcn_s_memtime() - t_enter > kernarg_params()->watchdog) { expired = true; break; }
+#else
                 if ((long long)(__builtin_amdgcn_s_memrealtime() - t_enter) > (long long)kernarg_params()->watchdog) { expired = true; break; }
+#endif
                 next_check = trips + 1024;
                 if (boost_on && level < RM_PRIO_LEVELS && tier(level) >= trips && tier(level) - trips < 1024) next_check = tier(level) + 1;
                 due = next_check < (uint32_t)RM_PRIMARY_STEPS ? next_check : (uint32_t)RM_PRIMARY_STEPS;
