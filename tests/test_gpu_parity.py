@@ -638,6 +638,20 @@ def test_incomplete_frame_is_reported(stock_scenes):
                 assert_same_frame(rm.read_pixels(), rm.read_hit_mask(), ref, "after_watchdog_%d" % k)
 
 
+def test_two_processes_share_the_gpu():
+    """Two processes rendering on this GPU at once (tools/two_process_stress.py): their wavefronts are preempted for
+    each other, and none may be stopped for it - with the watchdog on the per-XCD shader-cycle counter (rounds 1-2)
+    a preempted wavefront could find the counter behind its starting value and give up, which showed as
+    RM_ERR_INCOMPLETE in the 2-rank rehearsal (profiles/r03_two_process_stress.txt)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_process_stress.py"), "2", "360"],
+                       capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("pid ")]
+    assert len(lines) == 2 and all("360 launches, 0 checks failed" in ln for ln in lines), r.stdout
+
+
 def test_external_output_and_pitch(stock_scenes):
     """rm_set_output: render into a caller-owned device buffer with a padded pitch."""
     torch = pytest.importorskip("torch")
