@@ -11,10 +11,12 @@ before it is the ORDER in which its tiles are handed out, longest first).  Scene
 table and camera block are resident on the device before the timed region; the
 framebuffer stays in HBM.
 
-N = 1: one context, one stream, frames back to back (so the kernel's duration
-under rocprofv3 is the step time).  --in-flight F renders with F contexts taking
-frames in turn, each on its own stream: the tail of one frame then overlaps the
-head of the next (+13 % at 4K).
+N = 1: one context, one stream, launches of up to 32 frames back to back (so the kernel's duration
+under rocprofv3 is the launch's time).  A timed run is --repeats blocks of exactly --steps frames each,
+queued straight behind an untimed block of the same shape and behind each other; the MEDIAN block is
+`ms_per_step` and `value`, the others and every launch's own duration are in the line.
+--in-flight F renders with F contexts taking launches in turn, each on its own stream (no gain since
+launches hold 20-32 frames).
 
 N > 1: the frame is cut into row bands dealt round-robin to the ranks
 (raytracing_amd/tiling.py); each rank renders its bands, then one RCCL gather per
