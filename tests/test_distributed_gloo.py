@@ -1,4 +1,4 @@
-"""CPU suite, world_size 2 over gloo: the N>1 path of bench.py (row bands per rank,
+"""CPU suite, world_size 2 and 8 over gloo: the N>1 path of bench.py (row bands per rank,
 gather to rank 0, interleave) with the CPU restatement standing in for the render
 kernel.  The assembled frame must equal the single-rank frame byte for byte, both when
 RGBA8 rows travel and when the luminance planes of a launch of two frames do."""
@@ -49,7 +49,7 @@ def _worker(rank, world, port, w, h, band, out_path):
     # bench.py's transport: one byte per pixel (the blue channel is the luminance), the frames of a
     # launch in one gather, RGBA8 rebuilt on rank 0 (rm_set_luminance_output / rm_assemble_luminance_batch),
     # the bands dealt by weight: rank 0, which rebuilds, holds half of what rank 1 does (rm_set_band_pattern)
-    owner = tiling.deal([1, 2])
+    owner = tiling.deal(tiling.lighter_rank0(world, 0.5))            # 2 ranks: [1, 2]; 8 ranks: [1, 2, 2, 2, 2, 2, 2, 2]
     rows_max = tiling.max_local_rows(h, band, world, owner)
     infos = [info, O.default_info(3, 40)]
     slab = torch.zeros((len(infos), rows_max, w), dtype=torch.uint8)
@@ -69,11 +69,14 @@ def _worker(rank, world, port, w, h, band, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h,band", [(96, 70, 16), (64, 64, 32)])
-def test_two_rank_frame_equals_one_rank_frame(tmp_path, w, h, band):
+@pytest.mark.parametrize("world,w,h,band", [(2, 96, 70, 16), (2, 64, 64, 32), (8, 64, 203, 8)])
+def test_n_rank_frame_equals_one_rank_frame(tmp_path, world, w, h, band):
+    """(8 ranks, 8-row bands, a last band of 3 rows: the shape of the driver's 8-GPU run, on the CPU)"""
     from oracle import oracle as O
+    from raytracing_amd import tiling
+    assert tiling.lighter_rank0(2, 0.5) == [1, 2] and tiling.lighter_rank0(8, 0.5) == [1] + [2] * 7
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(2, _free_port(), w, h, band, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, band, out), nprocs=world, join=True)
     nodes = O.load_sce(os.path.join(ROOT, "tests", "golden", "scenes", "chair.sce"))
     want = O.render(nodes, w, h, O.default_info(1, 0))["rgba"]
     assert np.array_equal(np.load(out), want)
