@@ -110,7 +110,10 @@ int rm_set_info(rm_ctx* ctx, const rm_rays_info* info);
  * How many frames the next launch holds is set with the cameras: rm_set_info gives
  * all n frames the same block; rm_set_info_batch(ctx, infos, m) gives frame f the
  * f-th block and makes the launch m <= n frames long (a last launch that is not
- * full costs no reallocation, no wait and keeps the tile order learnt so far).
+ * full costs no reallocation, no wait and keeps the tile order learnt so far; a
+ * launch of more frames than the one before it takes that one's order for as many
+ * frames - for every group of them when it is a whole multiple, which is why a
+ * camera path is best started with a launch of one frame - and the rest in natural order).
  * Frame f writes its planes `*_frame_stride_bytes` after frame f-1's: RGBA8 output,
  * luminance plane; 0 = packed (pitch x rows of this context).  With the context's
  * own framebuffer rm_read_pixels returns frame 0.  rm_set_batch waits for the

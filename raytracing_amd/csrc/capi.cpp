@@ -65,7 +65,7 @@ struct rm_ctx {
     size_t blocks_per_cu_forced = 0;  // experiments (RM_BLOCKS_PER_CU, read by rm_create): 0 = what the kernel's occupancy allows
     bool feedback = true;             // launches file their tiles by cost for the next launch
     bool history = false;             // the previous launch did, with the same tile numbering...
-    size_t history_frames = 0;        // ...for this many frames: a launch of more frames starts in natural order
+    size_t history_frames = 0;        // ...for this many frames (a launch of more frames: fill_params, hist_tiles / list_reps)
     // completion accounting (kernel_params.h, RM_STATUS_*): tiles launched so far against tiles the
     // wavefronts report finished, both modulo 2^32
     uint32_t* status_host = nullptr;  // pinned copy of the device's status block
