@@ -561,6 +561,10 @@ def main():
             # are what `achieved` and `frac` are made of.  `reference_march` prices the same frames at the
             # reference's work (every ray marched to RM_MAX_DIST): the rate a kernel without windows would have to
             # sustain for this frame time - a speed-up figure, not a utilisation (it can exceed the peak).
+            # Since round 3 the kernel also shades a hit whose surface faces away from the light without marching its
+            # shadow ray (the reference multiplies that march's result by zero, Source/cuda_kernels.cu:694): the
+            # "windowed" counters restate that too (chair.sce 4K: 631 -> 555 FLOP per ray).  (With RM_RAY_WINDOWS=0,
+            # a diagnostic, the reference march's count is used and overstates what the kernel does by that much.)
             windows = os.environ.get("RM_RAY_WINDOWS", "1") != "0" and "windowed" in want
             done = want["windowed"] if windows else want
             per_launch = 1.0 / world * args.steps / launches
@@ -576,7 +580,7 @@ def main():
                                "reference_march": {"flops_per_ray": want["flops_per_ray"], "achieved": reference,
                                                    "frac": reference / FP32_VALU_PEAK_TFLOPS},
                                "note": "the path is bound by fp32 vector issue, not by HBM or MFMA (SURVEY.md 8d). "
-                                       "achieved = FLOPs the kernel executes in one launch (the windowed march's, counted by "
+                                       "achieved = FLOPs the kernel executes in one launch (the product's march - ray windows, no shadow march for unlit hits - counted by "
                                        "the CPU restatement; SURVEY.md appendix D: add/sub/mul/div/sqrt/floor/min/max = 1) "
                                        "over the kernel's average duration; peak = 157.3 TFLOP/s of FMAs.  reference_march: "
                                        "the same frames priced at the FLOPs of the reference's march, which takes every ray "

@@ -216,8 +216,9 @@ def render(nodes, width, height, info, threads=1, want_hit=True, want_evals=Fals
            want_counters=False, rows=None, window=None):
     """Render a frame (or rows=(y0,y1) of it, single-threaded) on the CPU.
 
-    window: an rm_scene_bound record (BOUND_DTYPE) - the product's windowed march restated
-    (rmo_render_windowed); None: the reference's march.
+    window: an rm_scene_bound record (BOUND_DTYPE) - the product's march restated (rmo_render_windowed: primary
+    rays marched only inside their ray window, hits that face away from the light shaded without their shadow
+    march; same pixels, fewer evaluations); None: the reference's march.
     Returns dict(rgba[H,W,4] u8, hit[H,W] u8, evals[H,W] u16, counters, seconds)."""
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     info = np.ascontiguousarray(info, dtype=INFO_DTYPE)

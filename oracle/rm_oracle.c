@@ -457,7 +457,10 @@ static uint8_t to_u8(float v, rmo_counters* c) {
 /* kernel_Process for one pixel, Source/cuda_kernels.cu:619-717 */
 /* t_end: RM_MAX_DIST for the reference's march; a ray window's end (rmo_ray_window) for the windowed one,
  * negative for a ray that is not marched at all. */
-static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float t_end,
+/* product: the march as the product's kernel makes it (raytracing_amd/csrc/device_render.h) - besides the ray window
+ * in t_end, a hit whose surface faces away from the light (N_L <= 0) is shaded without its shadow march, whose result
+ * :694 multiplies by zero.  Not the reference's march: it exists for the same two purposes as the windows (below). */
+static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float t_end, int product,
                           uint8_t px[4], uint8_t* hit, uint16_t* evals, rmo_counters* c) {
     float curr_dist, ray_dist = 0.f;
     rm_point curr_norm;
@@ -490,7 +493,7 @@ static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float 
                 ray_dist = (1 + RM_DELTA) * RM_MIN_DIST;
                 CNT(flops, 11);
 
-                for (int J = 0; J < RM_SHADOW_STEPS; ++J) {               /* :660 */
+                for (int J = 0; J < RM_SHADOW_STEPS && !(product && !(N_L > 0.f)); ++J) {   /* :660 */
                     curr_dist = rmo_dist(nodes, 0, p, c); ++nev;          /* :661 */
                     CNT(root_dist_shadow, 1);
                     if (8 * curr_dist < RM_MIN_DIST) {                    /* :662 */
@@ -593,7 +596,7 @@ void rmo_render_rows_windowed(const rm_node* nodes, size_t n, size_t width, size
             size_t i = y * width + x;
             float t_end = RM_MAX_DIST;
             if (window && !rmo_ray_window(window, r, &t_end)) t_end = -1.f;
-            process_pixel(nodes, r, light, t_end, rgba + 4 * i, hit ? hit + i : NULL,
+            process_pixel(nodes, r, light, t_end, window != NULL, rgba + 4 * i, hit ? hit + i : NULL,
                           evals ? evals + i : NULL, c);
         }
 }

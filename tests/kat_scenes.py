@@ -293,6 +293,12 @@ PIXELS = [
 ]
 
 
+# cases whose hit surface faces away from the light (N_L <= 0): the reference marches the shadow ray all the same; the
+# product's kernel shades such a pixel without that march (:694 multiplies its result by zero), so its trip count has no
+# shadow evaluations in it
+PIXELS_UNLIT = {"inside_start"}
+
+
 def pixel_cases(info_dtype):
     """[(name, table, rays_info block, rgba uint8[4], hit, primary evaluations, shadow evaluations)]"""
     out = []
