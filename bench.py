@@ -563,7 +563,7 @@ def main():
             # sustain for this frame time - a speed-up figure, not a utilisation (it can exceed the peak).
             # Since round 3 the kernel also shades a hit whose surface faces away from the light without marching its
             # shadow ray (the reference multiplies that march's result by zero, Source/cuda_kernels.cu:694): the
-            # "windowed" counters restate that too (chair.sce 4K: 631 -> 555 FLOP per ray).  (With RM_RAY_WINDOWS=0,
+            # "windowed" counters restate that too, and the shadow windows: chair.sce 4K 631 -> 532 FLOP per ray.  (With RM_RAY_WINDOWS=0,
             # a diagnostic, the reference march's count is used and overstates what the kernel does by that much.)
             windows = os.environ.get("RM_RAY_WINDOWS", "1") != "0" and "windowed" in want
             done = want["windowed"] if windows else want

@@ -457,11 +457,14 @@ static uint8_t to_u8(float v, rmo_counters* c) {
 /* kernel_Process for one pixel, Source/cuda_kernels.cu:619-717 */
 /* t_end: RM_MAX_DIST for the reference's march; a ray window's end (rmo_ray_window) for the windowed one,
  * negative for a ray that is not marched at all. */
-/* product: the march as the product's kernel makes it (raytracing_amd/csrc/device_render.h) - besides the ray window
- * in t_end, a hit whose surface faces away from the light (N_L <= 0) is shaded without its shadow march, whose result
- * :694 multiplies by zero.  Not the reference's march: it exists for the same two purposes as the windows (below). */
-static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float t_end, int product,
+/* window != NULL: the march as the product's kernel makes it (raytracing_amd/csrc/device_render.h) - besides the ray
+ * window in t_end, a hit whose surface faces away from the light (N_L <= 0) is shaded without its shadow march, whose
+ * result :694 multiplies by zero, and a shadow march ends where rmo_shadow_window proves that the rest of it can
+ * change nothing.  Not the reference's march: it exists for the same two purposes as the windows (below). */
+float rmo_shadow_window(const rm_scene_bound* b, rm_point o, rm_point l, float t0);
+static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float t_end, const rm_scene_bound* window,
                           uint8_t px[4], uint8_t* hit, uint16_t* evals, rmo_counters* c) {
+    const int product = window != NULL;
     float curr_dist, ray_dist = 0.f;
     rm_point curr_norm;
     unsigned nev = 0;
@@ -492,6 +495,7 @@ static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float 
                 p.z += (1 + RM_DELTA) * RM_MIN_DIST * light.z;
                 ray_dist = (1 + RM_DELTA) * RM_MIN_DIST;
                 CNT(flops, 11);
+                const float s_end = product && N_L > 0.f ? rmo_shadow_window(window, p, light, ray_dist) : RM_MAX_DIST;
 
                 for (int J = 0; J < RM_SHADOW_STEPS && !(product && !(N_L > 0.f)); ++J) {   /* :660 */
                     curr_dist = rmo_dist(nodes, 0, p, c); ++nev;          /* :661 */
@@ -520,7 +524,7 @@ static void process_pixel(const rm_node* nodes, rm_ray r, rm_point light, float 
                     p.z += curr_dist * light.z;
                     ray_dist += curr_dist;
                     CNT(flops, 7);
-                    if (ray_dist >= RM_MAX_DIST) break;                   /* :689-690 */
+                    if (ray_dist >= s_end) break;                         /* :689-690: RM_MAX_DIST */
                 }
 
                 /* :693-701 */
@@ -585,6 +589,41 @@ int rmo_ray_window(const rm_scene_bound* b, rm_ray r, float* t_end) {
     return !(usable && (gap < 0.f || leave < 0.f));
 }
 
+/* The product's shadow windows (device_render.h, shadow_window), restated: the ray_dist at which a shadow march that
+ * starts at o with ray_dist t0 and moves by cd * l per step may end, because from there on it is outside the grown volume
+ * for good, no sample can be near a surface and :679's quotient cannot fall below 1; RM_MAX_DIST where that is not proved. */
+float rmo_shadow_window(const rm_scene_bound* b, rm_point o, rm_point l, float t0) {
+    if (!b || b->kind == RM_BOUND_NONE) return RM_MAX_DIST;
+    const float R = b->r + RM_WINDOW_MARGIN;
+    const float ocx = o.x - b->c[0], ocy = o.y - b->c[1], ocz = o.z - b->c[2];
+    float px = ocx, py = ocy, pz = ocz, qx = l.x, qy = l.y, qz = l.z;
+    const float vv = l.x * l.x + l.y * l.y + l.z * l.z;
+    int usable = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= RM_WINDOW_MAX_COORD && vv >= 0x1p-20f && vv <= 0x1p20f;
+    float a = vv;
+    if (b->kind == RM_BOUND_CYLINDER) {
+        const float ux = b->u[0], uy = b->u[1], uz = b->u[2];
+        const float ou = ocx * ux + ocy * uy + ocz * uz, vu = l.x * ux + l.y * uy + l.z * uz;
+        px -= ou * ux; py -= ou * uy; pz -= ou * uz;
+        qx -= vu * ux; qy -= vu * uy; qz -= vu * uz;
+        a = qx * qx + qy * qy + qz * qz;
+        usable = usable && a >= RM_WINDOW_MIN_SIN2 * vv;
+    }
+    const float rs = 1.f / sqrtf(a), inv_a = rs * rs;
+    const float len = sqrtf(vv), si = len * rs, rlen = 1.f / len;
+    const float s0 = -(px * qx + py * qy + pz * qz) * inv_a;
+    const float wx = px + s0 * qx, wy = py + s0 * qy, wz = pz + s0 * qz;
+    const float p2 = wx * wx + wy * wy + wz * wz;
+    const float mag = fabsf(ocx) + fabsf(ocy) + fabsf(ocz) + R;
+    const float Re = R + 5e-6f * mag * si;
+    const float gap = Re * Re - p2;
+    const float s_leave = s0 + sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f;
+    const float t_end = t0 + s_leave + (RM_WINDOW_SLACK + 5e-6f * mag * (si * si) + 2e-6f * fabsf(s0 * len)) * rlen * 1.00001f;
+    const int proved = usable && gap > 0.f && s_leave > 0.f
+                       && t_end * (1.f / RM_HARDNESS) <= 4.5f
+                       && a * gap >= Re * Re * (1.02f * 1.02f / (RM_HARDNESS * RM_HARDNESS));
+    return proved ? t_end : RM_MAX_DIST;
+}
+
 void rmo_render_rows_windowed(const rm_node* nodes, size_t n, size_t width, size_t height,
                               const rm_rays_info* info, const rm_scene_bound* window, size_t y0, size_t y1,
                               uint8_t* rgba, uint8_t* hit, uint16_t* evals, rmo_counters* c) {
@@ -596,7 +635,7 @@ void rmo_render_rows_windowed(const rm_node* nodes, size_t n, size_t width, size
             size_t i = y * width + x;
             float t_end = RM_MAX_DIST;
             if (window && !rmo_ray_window(window, r, &t_end)) t_end = -1.f;
-            process_pixel(nodes, r, light, t_end, window != NULL, rgba + 4 * i, hit ? hit + i : NULL,
+            process_pixel(nodes, r, light, t_end, window, rgba + 4 * i, hit ? hit + i : NULL,
                           evals ? evals + i : NULL, c);
         }
 }

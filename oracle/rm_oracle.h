@@ -95,7 +95,8 @@ double rmo_render(const rm_node* nodes, size_t n, size_t width, size_t height,
  * DIST(root, x) >= dist(x, centre or axis) - r; a primary ray is marched only while it can be within
  * RM_WINDOW_MARGIN of it.  With a window record (of any kind, RM_BOUND_NONE included) the march is the PRODUCT's in
  * its second departure from the reference's too: a hit whose surface faces away from the light (N_L <= 0) is shaded
- * without its shadow march, whose result :694 multiplies by zero.  Two uses: tests check that the product march's
+ * without its shadow march, whose result :694 multiplies by zero, and a shadow march ends where the rest of it
+ * provably changes nothing (rmo_shadow_window).  Two uses: tests check that the product march's
  * frame equals the reference march's frame, and the counters give the FLOPs the product's kernel executes.
  * window == NULL: the reference's march. */
 int rmo_ray_window(const rm_scene_bound* window, rm_ray r, float* t_end);

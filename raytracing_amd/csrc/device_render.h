@@ -94,11 +94,59 @@ __device__ __forceinline__ bool ray_window(KernargParams* kp, P3 o, P3 v, float&
     const float mag = fabsf(ocx) + fabsf(ocy) + fabsf(ocz) + R;
     const float Re = R + 5e-6f * mag * si;
     const float gap = Re * Re - p2;                                // >= 0: the ray passes through the grown volume
+    // a tile none of whose rays comes near the volume (half of chair.sce's at 4K) is done here: where its rays would
+    // leave the volume is not worked out (wave-uniform branch; the asm keeps the rest behind it)
+    if (__builtin_amdgcn_ballot_w64(!(usable && gap < 0.f)) == 0) return false;
+    asm volatile("" ::: "memory");
     const float s_leave = s0 + __builtin_amdgcn_sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f;
     // in units of travelled distance: the march moves by cd * (v / |v|), rounded, and adds cd up
     const float leave = s_leave * len + (RM_WINDOW_SLACK + 5e-6f * mag * (si * si) + 2e-6f * fabsf(s0 * len));
     if (usable && leave < RM_MAX_DIST) t_end = leave;              // (false for NaN)
     return !(usable && (gap < 0.f || leave < 0.f));
+}
+
+// The same volume ends a SHADOW march early (round 3; :660-691 marches until ray_dist >= RAYS_MAX_DIST, 300 steps or
+// darkness).  A shadow ray starts on the surface, inside the volume, at o with ray_dist = t0, and moves by cd * l while
+// ray_dist grows by cd (l: LightSource as given, any length): ray_dist = t0 + s at o + s l.  Let it leave the grown
+// volume for good at s_leave.  From there on no sample can be near a surface (DIST > margin - drift > 4.9 > RAYS_MIN_DIST
+// / 8: :662 never fires), and :679's quotient 128 * DIST / ray_dist stays at 1 or above, so min() keeps SHADOW (<= 1) bit
+// for bit, provided that at the exit (a) ray_dist / 128 <= 4.5 - DIST is at least (distance to the axis) - r - drift = 4.9
+// there - and (b) the distance to the axis grows by at least 1.02 / 128 per unit of ray_dist - it is convex in s, so it
+// keeps growing at least that fast, and DIST with it.  Then nothing the rest of the march does can change SHADOW or end
+// it otherwise than by :689 or the step cap: the lane is shaded when ray_dist reaches t0 + s_leave (plus the window's
+// slack) exactly as it would be thousands of units further on.  s_end = RM_MAX_DIST where no such point is proved.
+__device__ __forceinline__ float shadow_window(KernargParams* kp, P3 o, P3 l, float t0) {
+    const uint32_t kind = kp->bound_kind;
+    if (kind == RM_BOUND_NONE) return RM_MAX_DIST;                 // wave-uniform
+    const float R = kp->bound_R;
+    const float ocx = o.x - kp->bound_c[0], ocy = o.y - kp->bound_c[1], ocz = o.z - kp->bound_c[2];
+    float px = ocx, py = ocy, pz = ocz, qx = l.x, qy = l.y, qz = l.z;
+    const float vv = l.x * l.x + l.y * l.y + l.z * l.z;
+    bool usable = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) <= RM_WINDOW_MAX_COORD && vv >= 0x1p-20f && vv <= 0x1p20f;
+    float a = vv;
+    if (kind == RM_BOUND_CYLINDER) {
+        const float ux = kp->bound_u[0], uy = kp->bound_u[1], uz = kp->bound_u[2];
+        const float ou = ocx * ux + ocy * uy + ocz * uz, vu = l.x * ux + l.y * uy + l.z * uz;
+        px -= ou * ux; py -= ou * uy; pz -= ou * uz;
+        qx -= vu * ux; qy -= vu * uy; qz -= vu * uz;
+        a = qx * qx + qy * qy + qz * qz;
+        usable = usable && a >= RM_WINDOW_MIN_SIN2 * vv;
+    }
+    const float rs = __builtin_amdgcn_rsqf(a), inv_a = rs * rs;
+    const float len = __builtin_amdgcn_sqrtf(vv), si = len * rs, rlen = __builtin_amdgcn_rcpf(len);
+    const float s0 = -(px * qx + py * qy + pz * qz) * inv_a;
+    const float wx = px + s0 * qx, wy = py + s0 * qy, wz = pz + s0 * qz;
+    const float p2 = wx * wx + wy * wy + wz * wz;
+    const float mag = fabsf(ocx) + fabsf(ocy) + fabsf(ocz) + R;
+    const float Re = R + 5e-6f * mag * si;
+    const float gap = Re * Re - p2;
+    const float s_leave = s0 + __builtin_amdgcn_sqrtf(fmaxf(gap, 0.f) * inv_a) * 1.00001f;
+    // in units of ray_dist (= of s): the window's spatial allowances over |l|
+    const float t_end = t0 + s_leave + (RM_WINDOW_SLACK + 5e-6f * mag * (si * si) + 2e-6f * fabsf(s0 * len)) * rlen * 1.00001f;
+    const bool proved = usable && gap > 0.f && s_leave > 0.f
+                        && t_end * (1.f / RM_HARDNESS) <= 4.5f                                    // (a)
+                        && a * gap >= Re * Re * (1.02f * 1.02f / (RM_HARDNESS * RM_HARDNESS));    // (b): d|w|/ds = sqrt(a gap) / Re at the exit
+    return proved ? t_end : RM_MAX_DIST;                           // (false for NaN)
 }
 
 template <class Scene>
@@ -425,7 +473,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                         pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
                         t += cd;
                     }
-                    left = (left | mask_of(t >= RM_MAX_DIST)) & m_s;       // (no lane is at its step cap before trip stop_s)
+                    left = (left | mask_of(t >= as_f(shaded))) & m_s;      // :689, or the shadow window's end; (no lane is at its step cap before trip stop_s)
                     if (left) {                                                        // :693-701
                         if (lanes(left)) {
                             float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
@@ -497,6 +545,9 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                             t = k;
                             deadline = trips + RM_SHADOW_STEPS;
                             turns = true;
+                            // where this lane's shadow march may end (shadow_window), kept in the register that will hold
+                            // its luminance once it is shaded: until then a marching lane's `shaded` says nothing
+                            shaded = as_u(shadow_window(kernarg_params(), pos, light, k));
                         } else {
                             // A surface that faces away from the light (N_L <= 0, or NaN): :694 multiplies SHADOW by
                             // (N_L > 0 ? N_L : 0) = 0, and SHADOW is finite whatever the shadow march does with it
@@ -552,7 +603,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
                     t += cd;
                 }
-                left_s |= mask_of(t >= RM_MAX_DIST);
+                left_s |= mask_of(t >= as_f(shaded));                // :689, or the shadow window's end
                 if (trips >= dl_min) {
                     left_s |= mask_of(trips >= deadline);
                     // nobody due within 16 trips: look again then; else at every trip (through this tail) until they are
