@@ -4,6 +4,7 @@
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -120,9 +121,10 @@ struct Fused {
     int region = 0, regions = 0;      // the block being emitted (0: none); blocks so far
     int glata_depth = 0;              // smooth combinators above the node being emitted
     bool in_norm = false;             // emitting the normal's pass
-    bool allow_skip = true;
+    bool allow_skip = true, allow_sphere_skip = true;
     Fused(const rm_node* nodes_, const DivisorSet* exact_) : nodes(nodes_), exact(exact_) {
         if (const char* env = std::getenv("RM_BOUND_SKIP")) allow_skip = std::atoi(env) != 0;      // experiments only
+        if (const char* env = std::getenv("RM_SPHERE_SKIP")) allow_sphere_skip = std::atoi(env) != 0;
     }
     bool usable(const Temp& t) const { return in_norm || t.region == 0 || t.region == region; }
 
@@ -144,6 +146,30 @@ struct Fused {
         auto it = pmemo.find(key);
         if (it != pmemo.end() && usable(it->second)) return it->second.var;
         const rm_node& nd = nodes[i];
+        // A transform that hands a component through unchanged (a movo with a +0 offset: x - (+0) is x, bit for
+        // bit; the axis of a rotaciox/y/z) keeps no copy of it: the march carries its temporaries from trip to
+        // trip in registers, and a copy there is a v_mov per trip.
+        bool same[3] = {false, false, false};
+        if (nd.type == RM_TYPE_MOVO) {
+            for (int k = 0; k < 3; ++k) { uint32_t bits; std::memcpy(&bits, &nd.f[k], 4); same[k] = bits == 0u; }
+        } else if (nd.type == RM_TYPE_ROTACIOX || nd.type == RM_TYPE_ROTACIOY || nd.type == RM_TYPE_ROTACIOZ) {
+            same[nd.type == RM_TYPE_ROTACIOX ? 0 : nd.type == RM_TYPE_ROTACIOY ? 1 : 2] = true;
+        }
+        if (same[0] || same[1] || same[2]) {
+            const std::string call = nd.type == RM_TYPE_MOVO ? "movo(" + pv + ", " + lit3(nd.f) + ")"
+                                     : std::string(nd.type == RM_TYPE_ROTACIOX ? "rotx(" : nd.type == RM_TYPE_ROTACIOY ? "roty(" : "rotz(") +
+                                           pv + ", " + lit(nd.f[0]) + ", " + lit(nd.f[1]) + ")";
+            std::string q = "P3{";
+            for (int k = 0; k < 3; ++k) {
+                const char* c = k == 0 ? ".x" : k == 1 ? ".y" : ".z";
+                std::string part = pv + c;
+                if (!same[k]) { part = new_f(); dist += "    " + part + " = " + call + c + ";\n"; }
+                q += (k ? ", " : "") + part;
+            }
+            q += "}";
+            pmemo[key] = Temp{q, in_norm ? 0 : region};
+            return q;
+        }
         const std::string q = new_p();
         std::string e;
         switch (nd.type) {
@@ -199,6 +225,33 @@ struct Fused {
                 const float m = std::min(nd.f[0], nd.f[1]);
                 *bound = m;
                 return m >= 0.f && m < 1e30f;
+            }
+            default: return false;
+            }
+        }
+    }
+
+    // a sphere under transforms only (sphere_skip in d() below): the transforms from the top, the leaf, and
+    // the least sum of squares that is sure to put the point outside the sphere
+    struct SphereLeaf { std::vector<size_t> transforms; size_t leaf = 0; float clear = 0.f; std::string point, sumsq, var; };
+    bool sphere_leaf(size_t i, SphereLeaf* out) const {
+        for (;;) {
+            const rm_node& nd = nodes[i];
+            switch (nd.type) {
+            case RM_TYPE_MOVO: case RM_TYPE_SENFINA_RIPETO: case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY:
+            case RM_TYPE_ROTACIOZ: case RM_TYPE_ROTACIOQ:
+                out->transforms.push_back(i);
+                i = kid(i, 0);
+                continue;
+            case RM_TYPE_SFERO: {
+                const float r = nd.f[0];
+                if (!(r >= 1e-12f && r <= 1e12f)) return false;        // r*r normal and finite; false for NaN
+                const double need = static_cast<double>(r) * static_cast<double>(r) * (1.0 + 0x1p-20);
+                float c = static_cast<float>(need);
+                if (static_cast<double>(c) < need) c = std::nextafterf(c, INFINITY);
+                out->leaf = i;
+                out->clear = c;
+                return true;
             }
             default: return false;
             }
@@ -310,8 +363,48 @@ struct Fused {
                 dist += "    if (!SKIP || (__builtin_amdgcn_ballot_w64(!(" + v + " > " + lit(bound) + ")) & amask) != 0) {\n";
                 region = ++regions;
                 ops.clear();
-                for (const auto& m : carved) ops.emplace_back(d(m.first, pv), m.second);
-                fold(ops, true, "        ");
+                // sphere_skip: where every carved-out solid is a sphere, its square root is behind a second test.
+                // With q = x*x + y*y + z*z as sfero_dist forms it, q >= clear (clear: r*r*(1 + 2^-20) rounded up)
+                // puts sqrt(q) two units in the last place above r or more, so the rounded root exceeds r and
+                // -(sqrt(q) - r) < 0.  Where that holds for every carved sphere and the other members' max is
+                // >= 0 (all marching lanes), max() returns that max bit for bit (a -0 included: the spheres' terms
+                // are below zero, not zeros).  Unlike the outer test this one passes AT the surface of the other
+                // members, where the normal's pass reads the spheres' distances to choose its branch: they are
+                // set to +infinity, which loses every comparison the true values (negated: below zero, below
+                // the winning member) lose, and ties with nothing.
+                std::vector<SphereLeaf> balls;
+                bool all_balls = allow_sphere_skip;
+                for (const auto& m : carved) {
+                    SphereLeaf b;
+                    if (!all_balls || !sphere_leaf(m.first, &b)) { all_balls = false; break; }
+                    balls.push_back(b);
+                }
+                if (all_balls) {
+                    std::string test = "__builtin_amdgcn_ballot_w64(!(" + v + " >= 0.f))";      // a ballot each: straight from the compares
+                    for (auto& b : balls) {
+                        std::string q = pv;
+                        for (size_t t : b.transforms) q = point(t, q);
+                        b.point = q;
+                        b.sumsq = "q" + std::to_string(counter++);
+                        dist += "        const float " + b.sumsq + " = " + q + ".x * " + q + ".x + " + q + ".y * " + q + ".y + " + q + ".z * " + q + ".z;\n";
+                        test += " | __builtin_amdgcn_ballot_w64(!(" + b.sumsq + " >= " + lit(b.clear) + "))";
+                    }
+                    for (auto& b : balls) b.var = new_f();
+                    dist += "        if (!SKIP || ((" + test + ") & amask) != 0) {\n";
+                    for (size_t k = 0; k < balls.size(); ++k) {
+                        const SphereLeaf& b = balls[k];
+                        dist += "            " + b.var + " = sqrt_exact(" + b.sumsq + ") - " + lit(nodes[b.leaf].f[0]) + ";\n";
+                        dmemo[std::make_pair(b.leaf, b.point)] = Temp{b.var, region};
+                        ops.emplace_back(b.var, carved[k].second);
+                    }
+                    fold(ops, true, "            ");
+                    dist += "        } else {\n";
+                    for (const auto& b : balls) dist += "            " + b.var + " = __builtin_inff();\n";
+                    dist += "        }\n";
+                } else {
+                    for (const auto& m : carved) ops.emplace_back(d(m.first, pv), m.second);
+                    fold(ops, true, "        ");
+                }
                 region = 0;
                 dist += "    }\n";
             }

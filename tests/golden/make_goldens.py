@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="also the 4K csg1024 frame (minutes of CPU)")
     ap.add_argument("--windowed-only", action="store_true",
                     help="only add the windowed march's counters to the frames already in frames.json (every one of them)")
+    ap.add_argument("--kat-only", action="store_true", help="only the node-level known answers (a scene added to kat_scenes.py)")
     args = ap.parse_args()
     threads = os.cpu_count() or 4
     O.build()
@@ -96,6 +97,8 @@ def main():
         kat[name + ".dist"] = O.dist_many(table, 0, pts).view(np.uint32)
         kat[name + ".norm"] = O.norm_many(table, 0, pts).view(np.uint32)
     np.savez_compressed(os.path.join(HERE, "node_kat.npz"), **kat)
+    if args.kat_only:
+        return
 
     # ---- kernel_SetRays known answers
     rays = {}

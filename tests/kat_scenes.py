@@ -48,6 +48,12 @@ SCENES = {
                     ("komplemento", (), ("kunigajo_2", (), ("movo", (0, 0, -3), ("sfero", (2,))), ("movo", (0, 0, 3), ("sfero", (1.5,)))))),
     "carved": ("komunajo_2", (), ("kubo", (6, 6, 6)),
                ("komplemento", (), ("kunigajo_3", (), ("movo", (5, 5, 0), S5), ("movo", (-6, 0, 4), ("sfero", (3,))), ("movo", (0, -6, 0), C34)))),
+    # sphere_skip of the generated code: every carved-out solid a sphere (under a movo with +0 and -0 offsets, a
+    # rotation's axis handed through), spheres that reach out through the box's faces, a second open member
+    "carved_spheres": ("komunajo_4", (), ("kubo", (6, 5, 6)), ("movo", (0, 0, 1), ("sfero", (8.5,))),
+                       ("komplemento", (), ("movo", (0, 0, -6), ("sfero", (4,)))),
+                       ("komplemento", (), ("kunigajo_2", (), ("rotacioZ", (COS, SIN), ("movo", (-0.0, 5.5, 0), ("sfero", (2.25,)))),
+                                            ("movo", (6, 0, 3), ("rotacioX", (COS, SIN), ("sfero", (1.5,))))))),
     "nested_frames": ("kunigajo_2", (),
                       ("movo", (3, 0, 0), ("komunajo_2", (), K345,
                                            ("rotacioX", (COS, SIN), ("kunigajo_2", (), S5, ("movo", (0, 4, 0), ("sfero", (3,))))))),

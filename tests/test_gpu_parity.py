@@ -301,7 +301,7 @@ def test_union_scenes_of_other_sizes(seed, leaves):
         assert_same_frame(rgba, hit, ref, "union_%d_%s" % (seed, path))
 
 
-@pytest.mark.parametrize("name", ["mixed_kinds", "carved", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
+@pytest.mark.parametrize("name", ["mixed_kinds", "carved", "carved_spheres", "nested_frames", "glata_nested", "portanta_nested", "ripeto_frames", "deep_values"])
 @pytest.mark.parametrize("path", ["jit", "jitprog", "program"])
 def test_kat_scene_frames(name, path):
     """Whole frames of the nested test scenes (LDS value slots, saved frames, bounding spheres)."""
