@@ -136,6 +136,58 @@ def random_tree(seed, depth=5):
     return ("kunigajo_3", (), moved(build(depth - 1)), moved(build(depth - 1)), moved(build(depth - 1)))
 
 
+def random_carved(seed):
+    """A seeded solid with spheres cut out of it, the shape of chair.sce: transforms over a komunajo of one or two
+    big solids and the komplemento of one to four spheres, each under transforms of its own (offsets that are +0, -0
+    or not, axis rotations), some reaching out through the solid's faces, some tangent to one another.  For the
+    generated code's sphere_skip: rays that graze faces, start in hollows and cross from one into the next."""
+    rng = np.random.default_rng(seed)
+
+    def f(lo, hi):
+        return float(np.float32(rng.uniform(lo, hi)))
+
+    def off(lo, hi):
+        k = rng.integers(0, 4)
+        return 0.0 if k == 0 else -0.0 if k == 1 else f(lo, hi)
+
+    def ball():
+        t = ("sfero", (f(1.5, 6),))
+        for _ in range(int(rng.integers(0, 3))):
+            k = rng.integers(0, 5)
+            if k < 3:
+                t = ("movo", (off(-7, 7), off(-7, 7), off(-7, 7)), t)
+            else:
+                a = f(-3, 3)
+                t = ("rotacio" + "XYZ"[rng.integers(0, 3)], (np.float32(np.cos(a)), np.float32(np.sin(a))), t)
+        return ("movo", (off(-7, 7), off(-7, 7), off(-7, 7)), t)
+
+    body = ("kubo", (f(4, 8), f(4, 8), f(4, 8))) if rng.random() < 0.7 else ("cilindro", (f(4, 7), f(4, 8)))
+    n = int(rng.integers(1, 5))
+    balls = [ball() for _ in range(n)]
+    if n == 1:
+        cut = ("komplemento", (), balls[0])
+    elif n == 4 or rng.random() < 0.5:
+        cut = ("komplemento", (), ("kunigajo_%d" % n, ()) + tuple(balls))
+    else:       # komplementoj one by one: the chain merges them
+        cut = None
+    members = [body]
+    if rng.random() < 0.4:
+        members.append(("movo", (f(-1, 1), f(-1, 1), f(-1, 1)), ("sfero", (f(7, 10),))))
+    if cut is not None:
+        members.append(cut)
+    else:
+        members += [("komplemento", (), b) for b in balls]
+    while len(members) > 4:
+        members.pop(1)
+    solid = ("komunajo_%d" % len(members), ()) + tuple(members) if len(members) > 1 else members[0]
+    a = f(-3, 3)
+    solid = ("rotacioQ", quaternion((f(-1, 1), f(-1, 1), f(0.1, 1)), a), solid) if rng.random() < 0.5 else solid
+    solid = ("movo", (f(-3, 3), off(-3, 3), off(-3, 3)), solid)
+    if rng.random() < 0.5:
+        solid = ("senfina_ripeto", (0, f(30, 45), f(-5, 5)), solid)
+    return solid
+
+
 def tables():
     return {name: Tree(t).table() for name, t in SCENES.items()}
 

@@ -205,6 +205,29 @@ def test_random_trees(seed):
         assert_same_frame(rgba, hit, ref, "fuzz_%d_%s" % (seed, path))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RM_CARVE_SEEDS", "16"))))
+def test_random_carved_solids(seed):
+    """Fuzz of the generated code's sphere_skip (jit.cpp): solids with spheres cut out of them (kat_scenes.random_carved),
+    a frame from a seeded camera and light on the three kernels, DIST and NORM at seeded points, against the oracle."""
+    table = scenes.Tree(kat_scenes.random_carved(500 + seed)).table()
+    pts = kat_scenes.points(96, seed=100 + seed)
+    want_d, want_n = O.dist_many(table, 0, pts), O.norm_many(table, 0, pts)
+    with api.Raymarching(64, 64) as rm:
+        rm.set_jit(2)
+        rm.set_nodes(table)
+        d_jit, n_jit = rm.eval_points(pts, 0, which=2, want_norm=True)
+    assert same_floats(d_jit, want_d) and same_floats(n_jit, want_n), "generated DIST / NORM differ from the oracle"
+    info = O.default_info(1 + seed % 7, (seed * 5) % 23)
+    info["StartPos"] = (-42.0 + seed % 5, 2.0 - seed % 3, 1.0 + seed % 4)
+    for v in ("StartWVec", "StartHVec"):
+        for a in "xyz":
+            info[v][a] *= np.float32(3)
+    ref = O.render(table, 192, 112, info)
+    for path in ("jit", "jitprog", "program"):
+        rgba, hit, _ = gpu_render(table, 192, 112, info, path)
+        assert_same_frame(rgba, hit, ref, "carved_%d_%s" % (seed, path))
+
+
 def test_set_rays_kat():
     """kernel_SetRays (Source/cuda_kernels.cu:730-762) fused into the kernel."""
     for (w, h, phi) in [(640, 480, 0), (1920, 1080, 37), (7680, 4320, 119), (33, 17, 5)]:
