@@ -352,6 +352,7 @@ __device__ __forceinline__ void stage_tree(const TreeNode* __restrict__ src, uin
 // Scene evaluator handed to render_body<> (device_render.h): program for DIST(root),
 // walker for normals and for DIST when prm.evaluator == 1.
 struct InterpScene {
+    static constexpr bool kNarrow = false;       // (device_render.h: the march loops mask their ballots instead)
     const Slot* program;
     const TreeNode* tree;
     float* stack;

@@ -177,15 +177,18 @@ __device__ __forceinline__ P3 rotq(P3 p, float xx, float xy, float xz, float yx,
 // differ only in the sign of a zero, which nothing downstream tells apart (no division by, square
 // root of or copysign from such a value; comparisons and sums of squares do not see it).
 template <bool ZX, bool ZY, bool ZZ>
+__device__ __forceinline__ float ripeto_dot(P3 p, float ax, float ay, float az) {
+    if (ZX && ZY) return az * p.z;
+    if (ZX && ZZ) return ay * p.y;
+    if (ZY && ZZ) return ax * p.x;
+    if (ZX) return ay * p.y + az * p.z;
+    if (ZY) return ax * p.x + az * p.z;
+    if (ZZ) return ax * p.x + ay * p.y;
+    return dot3(ax, ay, az, p.x, p.y, p.z);
+}
+template <bool ZX, bool ZY, bool ZZ>
 __device__ __forceinline__ P3 ripeto_t(P3 p, float ax, float ay, float az, float aa, float raa) {
-    float dot;
-    if (ZX && ZY) dot = az * p.z;
-    else if (ZX && ZZ) dot = ay * p.y;
-    else if (ZY && ZZ) dot = ax * p.x;
-    else if (ZX) dot = ay * p.y + az * p.z;
-    else if (ZY) dot = ax * p.x + az * p.z;
-    else if (ZZ) dot = ax * p.x + ay * p.y;
-    else dot = dot3(ax, ay, az, p.x, p.y, p.z);
+    const float dot = ripeto_dot<ZX, ZY, ZZ>(p, ax, ay, az);
     float N = floorf(div_const_for_floor(dot, aa, raa) + .5f);
     return P3{ZX ? p.x : p.x - N * ax, ZY ? p.y : p.y - N * ay, ZZ ? p.z : p.z - N * az};
 }

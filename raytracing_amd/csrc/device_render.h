@@ -149,6 +149,10 @@ __device__ __forceinline__ float shadow_window(KernargParams* kp, P3 o, P3 l, fl
     return proved ? t_end : RM_MAX_DIST;                           // (false for NaN)
 }
 
+#ifndef RM_NARROW_EXEC
+#define RM_NARROW_EXEC 1
+#endif
+
 template <class Scene>
 __device__ __forceinline__ void render_body(const RenderParams& prm) {
     Scene scene;
@@ -433,6 +437,40 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             // anything else leaves its loop evaluated (trips, at, cd, keep) and the general tail finishes it.
             if (m_s == 0) {
                 // ---- primary lanes only (:707-714)
+                if constexpr (RM_NARROW_EXEC && Scene::kNarrow) {
+                // The loop runs with the marching lanes as its execution mask: a compare inside it is a ballot over those
+                // lanes as it stands, and a test on one is a branch on VCC - one scalar instruction where masking the
+                // ballot with m_p, comparing and branching took three.  The CU's scalar unit serves four SIMDs and was as
+                // busy as the vector units (infinity.sce: 7.3 G scalar instructions and branches a launch at one per cycle
+                // and CU are the launch's 11.4 ms).  Every exit is wave-level.  `t >= t_lim` (:712) is looked at before
+                // the next evaluation instead of behind the step: the same lanes leave with the same state, and the exit
+                // says by itself whether a trip is in flight (no lane past its limit) or not.
+                // (The trip count stays in a scalar register inside the region and leaves it through a vector register,
+                // read back from a lane that ran the loop: a scalar the region changed is, to the compiler, a value per
+                // lane behind it, and it would count in a vector register in the loop as well.)
+                uint32_t trips_out = 0;
+                const uint32_t due_s = uniform(due);
+                if (lanes(m_p)) {
+                    uint32_t n = trips;
+                    for (;;) {
+                        if (__builtin_amdgcn_ballot_w64(t >= t_lim)) break;                    // between trips: lanes leave
+                        asm("s_add_u32 %0, %0, 1" : "+s"(n) : : "scc");                        // ++trips
+                        at = pos;
+                        cd = scene.dist_keep(at, scratch, ~0ull, keep);                        // DIST(root, pos) (:627)
+                        if (__builtin_amdgcn_ballot_w64(cd < RM_MIN_DIST)) break;              // at a surface (:629); trip in flight
+                        asm volatile("" ::: "memory");
+                        if (n >= due_s) break;                                                 // trip in flight
+                        pos.x += cd * rd.x; pos.y += cd * rd.y; pos.z += cd * rd.z;
+                        t += cd;
+                    }
+                    asm("v_mov_b32 %0, %1" : "=v"(trips_out) : "s"(n));
+                }
+                trips = (uint32_t)__builtin_amdgcn_readlane((int)trips_out, (int)__builtin_ctzll(m_p));
+                {
+                    const unsigned long long left = __builtin_amdgcn_ballot_w64(t >= t_lim) & m_p;
+                    if (left) { m_p &= ~left; continue; }
+                }
+                } else {
                 for (;;) {
                     ++trips;
                     at = pos;
@@ -447,8 +485,51 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                     m_p &= ~__builtin_amdgcn_ballot_w64(t >= t_lim);           // a resting lane's stale t clears a bit that is clear
                     if (m_p == 0) break;
                 }
+                }
             } else if (m_p == 0) {
                 // ---- shadow lanes only (:679-690)
+                if constexpr (RM_NARROW_EXEC && Scene::kNarrow) {
+                // (as above: the marching lanes are the execution mask, every exit is wave-level, and the ends of :680-690
+                // are looked at between trips - before the next evaluation, or straight behind the quotient that darkened a lane)
+                uint32_t trips_out = 0;
+                const uint32_t stop_u = uniform(stop_s);
+                if (lanes(m_s)) {
+                    uint32_t n = trips;
+                    for (;;) {
+                        if (__builtin_amdgcn_ballot_w64(t >= as_f(shaded))) break;             // between trips: :689, or the shadow window's end
+                        asm("s_add_u32 %0, %0, 1" : "+s"(n) : : "scc");
+                        at = pos;
+                        cd = scene.dist_keep(at, scratch, ~0ull, keep);                        // :661
+                        if (__builtin_amdgcn_ballot_w64(cd < kShadowNear)) break;              // at a surface (:662); trip in flight
+                        asm volatile("" ::: "memory");
+                        if (n >= stop_u) break;                                                // trip in flight
+                        bool dark = false;
+                        if (__builtin_amdgcn_ballot_w64(!(cd * kHardnessLow > shadow * t))) {
+                            float ns = RM_HARDNESS * cd;
+                            asm volatile("; shadow quotient" : "+v"(ns));       // keeps the division behind the branch
+                            shadow = min2(shadow, ns / t);
+                            dark = __builtin_amdgcn_ballot_w64(shadow < 0.01f) != 0;           // :680
+                        }
+                        pos.x += cd * light.x; pos.y += cd * light.y; pos.z += cd * light.z;
+                        t += cd;
+                        if (dark) break;                                                       // between trips
+                    }
+                    asm("v_mov_b32 %0, %1" : "=v"(trips_out) : "s"(n));
+                }
+                trips = (uint32_t)__builtin_amdgcn_readlane((int)trips_out, (int)__builtin_ctzll(m_s));
+                {
+                    // (a marching lane's shadow is >= .01 until a quotient lowers it, and no lane is at its step cap before trip stop_s)
+                    const unsigned long long left = (mask_of(t >= as_f(shaded)) | mask_of(shadow < 0.01f)) & m_s;
+                    if (left) {                                                                // :693-701
+                        if (lanes(left)) {
+                            float lum = 255.f * (RM_MIN_LUM + (RM_MAX_LUM - RM_MIN_LUM) * (n_l > 0.f ? n_l : 0.f) * shadow);
+                            shaded = 0x100u | to_u8(lum);
+                        }
+                        m_s &= ~left;
+                        continue;
+                    }
+                }
+                } else {
                 for (;;) {
                     ++trips;
                     at = pos;
@@ -483,6 +564,7 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                         if (m_s == 0) break;
                     }
                 }
+                }
             } else {
                 // ---- lanes in both phases: one evaluation serves them all (:627 and :661)
                 ++trips;
@@ -492,6 +574,9 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
             if ((m_p | m_s) == 0) break;
 
             // ---- the general tail
+#ifdef RM_STATS_GENERAL            // diagnostics (RM_JIT_FLAGS): rm_debug_wave_stats' fourth word counts the trips that end here
+            ++st_norm_cycles;
+#endif
             // a tile that runs long goes first on its SIMD from trip boost_age + 1 on (the long tiles set the
             // length of the frame), and the watchdog looks at the clock every 1024 trips
             if (trips >= next_check) {
@@ -564,7 +649,9 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
                 unlit = __builtin_amdgcn_ballot_w64(dark);
                 if (turn && trips + RM_SHADOW_STEPS < dl_min) dl_min = trips + RM_SHADOW_STEPS;
                 occluded = __builtin_amdgcn_ballot_w64(hidden);
+#ifndef RM_STATS_GENERAL
                 if (prm.wave_stats) st_norm_cycles += (uint32_t)(__builtin_amdgcn_s_memtime() - st_n0);
+#endif
             }
 
             // ---- primary lanes march on (:707-714), those that did not just turn to the light

@@ -4,6 +4,7 @@
 #include <hip/hiprtc.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -121,10 +122,44 @@ struct Fused {
     int region = 0, regions = 0;      // the block being emitted (0: none); blocks so far
     int glata_depth = 0;              // smooth combinators above the node being emitted
     bool in_norm = false;             // emitting the normal's pass
-    bool allow_skip = true, allow_sphere_skip = true;
+    bool allow_skip = true, allow_sphere_skip = true, allow_cell_cache = true;
+    std::string cache_decl;           // struct SceneCache: the lattices' cells, kept from one evaluation to the next
     Fused(const rm_node* nodes_, const DivisorSet* exact_) : nodes(nodes_), exact(exact_) {
         if (const char* env = std::getenv("RM_BOUND_SKIP")) allow_skip = std::atoi(env) != 0;      // experiments only
         if (const char* env = std::getenv("RM_SPHERE_SKIP")) allow_sphere_skip = std::atoi(env) != 0;
+        if (const char* env = std::getenv("RM_CELL_CACHE")) cell_cache_forced = std::atoi(env);
+    }
+    int cell_cache_forced = -1;       // RM_CELL_CACHE (experiments): 0 never, 1 always
+    // cell_cache keeps one to four values per lattice and lane alive across trips.  It is used where the lattices are
+    // a large part of an evaluation (infinity.sce: half of it) and left out where they are a small one and the registers
+    // are worth more (chair.sce: 7 %, and the kernel no longer fits eight wavefronts per SIMD with it: measured 66.5 with,
+    // 69.2 Grays/s without).  The shares come from a rough count of vector instructions per node type.
+    void weigh_lattices(size_t n, const unsigned char* seen) {
+        double total = 0.0, saved = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            if (!seen[i]) continue;
+            const rm_node& nd = nodes[i];
+            switch (nd.type) {
+            case RM_TYPE_SFERO: total += 13; break;
+            case RM_TYPE_KUBO: total += 19; break;
+            case RM_TYPE_CILINDRO: total += 40; break;
+            case RM_TYPE_EBENO: total += 6; break;
+            case RM_TYPE_PORTANTA_SFERO: total += 14; break;
+            case RM_TYPE_MOVO: total += 3; break;
+            case RM_TYPE_ROTACIOX: case RM_TYPE_ROTACIOY: case RM_TYPE_ROTACIOZ: total += 6; break;
+            case RM_TYPE_ROTACIOQ: total += 18; break;
+            case RM_TYPE_GLATA_KUNIGAJO_2: case RM_TYPE_GLATA_KOMUNAJO_2: total += 20; break;
+            case RM_TYPE_SENFINA_RIPETO: {
+                int nz = 0;
+                for (int k = 0; k < 3; ++k) nz += nd.f[k] != 0.f;
+                total += nz <= 1 ? 9 : 9 + 2 * nz;
+                if (cell_cacheable(nd)) saved += 6.5;
+                break;
+            }
+            default: total += node_arity(nd.type) > 1 ? node_arity(nd.type) - 1 : 0; break;
+            }
+        }
+        allow_cell_cache = cell_cache_forced >= 0 ? cell_cache_forced != 0 : saved >= 0.15 * total;
     }
     bool usable(const Temp& t) const { return in_norm || t.region == 0 || t.region == region; }
 
@@ -140,12 +175,128 @@ struct Fused {
         return q;
     }
 
+    std::string new_c() { std::string v = "c" + std::to_string(counter++); cache_decl += "    float " + v + " = 0.f;\n"; return "s." + v; }
+
+    // cell_cache (round 3).  senfina_ripeto takes N = floor(dot(a, p) / dot(a, a) + .5f) lattice vectors off the point
+    // (:577-581): a quotient, a floor and their guard, a fifth of chair.sce's step and half of infinity.sce's, and from
+    // one evaluation to the next N almost never changes (99.9 % of infinity.sce's, lane by lane).  N is a monotonic
+    // function of the rounded dot product d alone (a rounded quotient by a constant, a rounded sum, a floor), so every d
+    // with |d - N aa| <= aa (.5 - E) gives the N it is tested against, where E covers the roundings between d and the
+    // floor's argument ((|N| + 1) 2^-23) and those of the test itself ((|N| + 1) 2^-24): E = 129 * 2^-21 for |N| <= 127,
+    // 2.7 times what is needed.  For a lattice along one axis d is monotonic in that coordinate and the test is on the
+    // reduced coordinate itself: |p.z - N a.z| < |a.z| (.5 - E) (the same E covers A p.z, A A and N A rounded).
+    // Each lane keeps N a (and N aa) of its last full evaluation (struct SceneCache, a few registers that live across
+    // trips and tiles: an entry is valid for any point that passes its test, whatever ray it came from).  A trip takes
+    // the reduced point p - N a - the reference's own subtraction, N a being the product it forms - and one wave-wide
+    // test; where a marching lane fails it the whole wave takes the reference's arithmetic and refreshes its entries.
+    // An N beyond 127 is stored as +infinity, which fails every test.
+    static constexpr double kCellMargin = 129.0 / 2097152.0;
+    bool cell_cacheable(const rm_node& nd) const {
+        if (!allow_cell_cache || nd.type != RM_TYPE_SENFINA_RIPETO) return false;
+        int nz = 0;
+        for (int k = 0; k < 3; ++k) {
+            const float a = std::fabs(nd.f[k]);
+            if (!(a == a) || a > 1e6f || (a != 0.f && a < 1e-6f)) return false;
+            nz += a != 0.f;
+        }
+        const float aa = ripeto_aa(nd);
+        return nz >= 1 && aa >= 1e-12f && aa <= 1e12f;
+    }
+    static float round_down(double v) {      // the largest float not above v (v > 0)
+        float f = static_cast<float>(v);
+        if (static_cast<double>(f) > v) f = std::nextafterf(f, 0.f);
+        return f;
+    }
+    // the chain of lattices that starts at node i (each the only child of the one before), on the point pv
+    std::string cached_lattices(size_t i, const std::string& pv) {
+        struct Link { size_t node; std::string in, out, dot_args, e, mid; std::string t[3], o[3]; int nz = 0, axis = -1; float thr = 0.f; };
+        std::vector<Link> links;
+        std::string in = pv;
+        for (size_t at = i; cell_cacheable(nodes[at]); at = kid(at, 0)) {
+            const rm_node& nd = nodes[at];
+            Link l; l.node = at; l.in = in;
+            l.out = "P3{";
+            for (int k = 0; k < 3; ++k) {
+                const char* c = k == 0 ? ".x" : k == 1 ? ".y" : ".z";
+                if (nd.f[k] != 0.f) { l.t[k] = new_f(); l.o[k] = new_c(); ++l.nz; l.axis = k; l.out += (k ? ", " : "") + l.t[k]; }
+                else l.out += (k ? ", " : "") + in + c;
+            }
+            l.out += "}";
+            auto z = [](float v) { return v == 0.f ? "true" : "false"; };
+            l.dot_args = std::string("<") + z(nd.f[0]) + ", " + z(nd.f[1]) + ", " + z(nd.f[2]) + ">(";
+            const double aa = static_cast<double>(ripeto_aa(nd));
+            if (l.nz == 1) l.thr = round_down(std::fabs(static_cast<double>(nd.f[l.axis])) * (0.5 - kCellMargin));
+            else { l.thr = round_down(aa * (0.5 - kCellMargin)); l.mid = new_c(); l.e = "e" + std::to_string(counter++); }
+            links.push_back(l);
+            in = l.out;
+            if (node_arity(nodes[at].type) != 1) break;
+        }
+        auto dot_of = [&](const Link& l) { return "ripeto_dot" + l.dot_args + l.in + ", " + lit3(nodes[l.node].f) + ")"; };
+        // ---- the reduced points by the cells kept, and the test
+        std::vector<std::string> ballots;
+        std::vector<std::pair<float, std::vector<std::string>>> single;      // one-axis tests by threshold
+        for (const Link& l : links) {
+            for (int k = 0; k < 3; ++k)
+                if (!l.t[k].empty()) dist += "    " + l.t[k] + " = " + l.in + (k == 0 ? ".x" : k == 1 ? ".y" : ".z") + " - " + l.o[k] + ";\n";
+            if (l.nz == 1) {
+                bool filed = false;
+                for (auto& g : single) if (g.first == l.thr && g.second.size() < 3) { g.second.push_back(l.t[l.axis]); filed = true; break; }
+                if (!filed) single.push_back({l.thr, {l.t[l.axis]}});
+            } else {
+                dist += "    const float " + l.e + " = " + dot_of(l) + ";\n";
+                ballots.push_back("__builtin_amdgcn_ballot_w64(!(fabsf(" + l.e + " - " + l.mid + ") < " + lit(l.thr) + "))");
+            }
+        }
+        for (const auto& g : single) {
+            std::string w = g.second[0];
+            if (g.second.size() > 1) {      // the largest magnitude of the group, one instruction (written out: see the combinators)
+                w = "w" + std::to_string(counter++);
+                dist += "    float " + w + ";\n";
+                if (g.second.size() == 2)
+                    dist += "    asm(\"v_max_f32_e64 %0, |%1|, |%2|\" : \"=v\"(" + w + ") : \"v\"(" + g.second[0] + "), \"v\"(" + g.second[1] + "));\n";
+                else
+                    dist += "    asm(\"v_max3_f32 %0, |%1|, |%2|, |%3|\" : \"=v\"(" + w + ") : \"v\"(" + g.second[0] + "), \"v\"(" + g.second[1] +
+                            "), \"v\"(" + g.second[2] + "));\n";
+            }
+            ballots.push_back("__builtin_amdgcn_ballot_w64(!(fabsf(" + w + ") < " + lit(g.first) + "))");
+        }
+        std::string test;
+        for (size_t k = 0; k < ballots.size(); ++k) test += (k ? " | " : "") + ballots[k];
+        // ---- some marching lane has left a cell (or holds none): the reference's arithmetic for the wave, cells refreshed
+        dist += "    if (!SKIP || ((" + test + ") & amask) != 0) {\n";
+        for (size_t j = 0; j < links.size(); ++j) {
+            const Link& l = links[j];
+            const rm_node& nd = nodes[l.node];
+            const float aa = ripeto_aa(nd);
+            const std::string id = std::to_string(counter++), n = "n" + id, ok = "ok" + id;
+            const std::string d = (j == 0 && l.nz > 1) ? l.e : dot_of(l);
+            dist += "        const float " + n + " = floorf(div_const_for_floor(" + d + ", " + lit(aa) + ", " + lit(divisor_reciprocal(exact, aa)) + ") + .5f);\n";
+            dist += "        const bool " + ok + " = fabsf(" + n + ") <= 127.f;\n";
+            for (int k = 0; k < 3; ++k) {
+                if (l.t[k].empty()) continue;
+                const std::string o = "o" + std::to_string(counter++);
+                dist += "        const float " + o + " = " + n + " * " + lit(nd.f[k]) + ";\n";
+                dist += "        " + l.t[k] + " = " + l.in + (k == 0 ? ".x" : k == 1 ? ".y" : ".z") + " - " + o + ";\n";
+                dist += "        " + l.o[k] + " = " + ok + " ? " + o + " : __builtin_inff();\n";
+            }
+            if (l.nz > 1) dist += "        " + l.mid + " = " + ok + " ? " + n + " * " + lit(aa) + " : __builtin_inff();\n";
+        }
+        dist += "    }\n";
+        std::string first;
+        for (const Link& l : links) {
+            pmemo[std::make_pair(l.node, l.in)] = Temp{l.out, region};
+            if (first.empty()) first = l.out;
+        }
+        return first;
+    }
+
     // the point node i hands to its child, for i a transform (or a portanta_sfero)
     std::string point(size_t i, const std::string& pv) {
         const auto key = std::make_pair(i, pv);
         auto it = pmemo.find(key);
         if (it != pmemo.end() && usable(it->second)) return it->second.var;
         const rm_node& nd = nodes[i];
+        if (!in_norm && cell_cacheable(nd)) return cached_lattices(i, pv);
         // A transform that hands a component through unchanged (a movo with a +0 offset: x - (+0) is x, bit for
         // bit; the axis of a rotaciox/y/z) keeps no copy of it: the march carries its temporaries from trip to
         // trip in registers, and a copy there is a v_mov per trip.
@@ -503,16 +654,18 @@ struct Fused {
         }
     }
 
-    std::string source() {
+    std::string source(size_t count, const unsigned char* seen) {
+        weigh_lattices(count, seen);
         const std::string root = d(0, "E");
         in_norm = true;
         n(0, "E", "N", 1);
         // SKIP: the blocks of bound_skip may be skipped (amask: the lanes whose distance matters).  The march asks
         // with SKIP = true; a caller that takes normals at points of its own choosing (known-answer hook) with false.
         return "struct SceneKeep {\n" + decl + "};\n"
+               "struct SceneCache {\n" + cache_decl + "};\n"
                "template <bool SKIP>\n"
-               "__device__ __forceinline__ float scene_dist_keep(P3 E, SceneKeep& k, unsigned long long amask) {\n" + dist +
-               "    (void)amask;\n    return " + root + ";\n}\n"
+               "__device__ __forceinline__ float scene_dist_keep(P3 E, SceneKeep& k, SceneCache& s, unsigned long long amask) {\n" + dist +
+               "    (void)amask; (void)s;\n    return " + root + ";\n}\n"
                "__device__ __forceinline__ P3 scene_norm_keep(P3 E, const SceneKeep& k) {\n    P3 N{0.f, 0.f, 0.f};\n" + norm +
                "    (void)E; (void)k;\n    return N;\n}\n";
     }
@@ -627,6 +780,7 @@ std::string generate_scene_source(const rm_node* nodes, size_t n, const unsigned
         s += program_function(*program, value_slots);
         s += R"(
 struct JitScene {
+    static constexpr bool kNarrow = false;
     struct Scratch {};
     struct Keep {};
     __device__ __forceinline__ void init(const RenderParams&) {}
@@ -639,14 +793,15 @@ struct JitScene {
 )";
     } else {
         Fused fused(nodes, exact);
-        s += fused.source();
+        s += fused.source(n, seen);
         s += R"(
 struct JitScene {
-    struct Scratch {};
+    typedef SceneCache Scratch;
     typedef SceneKeep Keep;
+    static constexpr bool kNarrow = true;        // the march loops run with the marching lanes as their execution mask (device_render.h)
     __device__ __forceinline__ void init(const RenderParams&) {}
-    __device__ __forceinline__ float dist_keep(P3 p, Scratch&, unsigned long long amask, Keep& k) { return scene_dist_keep<true>(p, k, amask); }
-    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch&, unsigned long long, Keep& k) { return scene_dist_keep<false>(p, k, ~0ull); }
+    __device__ __forceinline__ float dist_keep(P3 p, Scratch& s, unsigned long long amask, Keep& k) { return scene_dist_keep<true>(p, k, s, amask); }
+    __device__ __forceinline__ float dist_keep_all(P3 p, Scratch& s, unsigned long long, Keep& k) { return scene_dist_keep<false>(p, k, s, ~0ull); }
     __device__ __forceinline__ P3 norm_keep(P3 p, Scratch&, const Keep& k) { return scene_norm_keep(p, k); }
 };
 }  // namespace rm
@@ -846,7 +1001,9 @@ std::string grouped_function(const std::vector<Slot>& program, const UnionGroups
         s += "    (void)tx; (void)ty; (void)P; (void)brank;\n    Aout = A;\n    return best;\n}\n";
     } else {
         s += "    // the next call starts with the group that holds the minimum of the first marching lane\n";
-        s += "    if (amask) first = (uint32_t)__builtin_amdgcn_readlane((int)bestg, (int)__builtin_ctzll(amask));\n";
+        s += "    // (amask all ones: the caller runs with the marching lanes as its execution mask)\n";
+        s += "    if (amask == ~0ull) first = (uint32_t)__builtin_amdgcn_readfirstlane((int)bestg);\n";
+        s += "    else if (amask) first = (uint32_t)__builtin_amdgcn_readlane((int)bestg, (int)__builtin_ctzll(amask));\n";
         s += "    (void)tx; (void)ty; (void)P;\n    return A;\n}\n";
     }
     return s;
@@ -880,6 +1037,7 @@ std::string generate_program_source(const std::vector<Slot>& program, uint32_t v
         // inline every sub-tree's distance code at every level
         s += R"(
 struct JitScene {
+    static constexpr bool kNarrow = false;
     const TreeNode* tree;
     typedef WalkStack Scratch;
     __device__ __forceinline__ void init(const RenderParams& prm) {
@@ -947,6 +1105,7 @@ struct JitScene {
     s += "    return N;\n}\n";
     s += std::string(R"(
 struct JitScene {
+    static constexpr bool kNarrow = false;
     struct Scratch { uint32_t first = 0; };      // the group to visit first (wave-uniform)
     __device__ __forceinline__ void init(const RenderParams&) {}
     struct Keep {};
@@ -1083,23 +1242,33 @@ hipError_t jit_compile(int device, const std::string& scene_source, size_t lds_b
     e = hipSetDevice(device);
     if (e != hipSuccess) return e;
     if (code.empty()) {
+        const auto t_build = std::chrono::steady_clock::now();
         (void)jit_build_code(arch, source, &code, log);
         if (code.empty()) return hipErrorInvalidSource;
+        const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
         // A kernel whose vector registers allow eight wavefronts per SIMD is held to six by its
         // scalar registers (measured on MI355X: 106 SGPRs -> 6 resident, <= 96 -> 7, <= 80 -> 8,
         // whatever the occupancy query says).  Such a kernel is built again with the compiler told
         // to fit eight; the spilled scalars cost less than the two wavefronts bring (infinity.sce
         // 4K 1.105 -> 1.056 ms).  A kernel a few registers above 64 is tried too (chair.sce: 67 -> 64, nothing
         // spilled to memory); the second build is kept only if it fits 64 without scratch.
-        if (load_module(code, lds_bytes, &k) == hipSuccess && k.vgprs > 0 && k.vgprs <= 72 && k.scratch == 0 &&
+        // (a kernel further above 64 registers, and the seven-wave build, only where a build takes a few seconds:
+        // a union of hundreds of primitives compiles for half a minute a time)
+        const bool quick = build_s < 5.0;
+        if (load_module(code, lds_bytes, &k) == hipSuccess && k.vgprs > 0 && k.vgprs <= (quick ? 96 : 72) && k.scratch == 0 &&
             !(flags && std::strstr(flags, "RM_KERNEL_ATTR"))) {
-            std::vector<char> tight;
-            JitKernels k2;
-            std::string log2;
-            if (jit_build_code(arch, "#define RM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))\n" + source, &tight, &log2) &&
-                load_module(tight, lds_bytes, &k2) == hipSuccess && k2.vgprs <= 64 && k2.scratch == 0)
-                code.swap(tight);
-            if (k2.module) (void)hipModuleUnload(k2.module);
+            // (eight wavefronts in 64 registers, else seven in 72 - where the eight-wave build has to spill to memory)
+            const int fit[2][2] = {{8, 64}, {7, 72}};
+            for (int a = 0; a < (quick ? 2 : 1); ++a) {
+                std::vector<char> tight;
+                JitKernels k2;
+                std::string log2;
+                const std::string w = std::to_string(fit[a][0]);
+                const bool ok = jit_build_code(arch, "#define RM_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(" + w + ", " + w + ")))\n" + source, &tight, &log2) &&
+                                load_module(tight, lds_bytes, &k2) == hipSuccess && k2.vgprs <= fit[a][1] && k2.scratch == 0;
+                if (k2.module) (void)hipModuleUnload(k2.module);
+                if (ok) { code.swap(tight); break; }
+            }
         }
         if (k.module) (void)hipModuleUnload(k.module);
         k = JitKernels();
