@@ -427,6 +427,9 @@ __device__ __forceinline__ void render_body(const RenderParams& prm) {
         // lanes also the step cap of :626).
         uint32_t due = next_check < (uint32_t)RM_PRIMARY_STEPS ? next_check : (uint32_t)RM_PRIMARY_STEPS;
         uint32_t stop_s = next_check;            // shadow-only trips: min(next_check, dl_min)
+#ifdef RM_EXPERIMENT_NO_MARCH                    // measurements only (RM_JIT_FLAGS): what a launch costs without its marches
+        m_p = 0;
+#endif
         while (m_p | m_s) {
             P3 at;
             typename Scene::Keep keep;
