@@ -163,8 +163,28 @@ struct Fused {
     }
     bool usable(const Temp& t) const { return in_norm || t.region == 0 || t.region == region; }
 
-    std::string new_f() { std::string v = "d" + std::to_string(counter++); decl += "    float " + v + ";\n"; return "k." + v; }
-    std::string new_p() { std::string v = "p" + std::to_string(counter++); decl += "    P3 " + v + ";\n"; return "k." + v; }
+    // lean: the normal's pass re-uses the distance pass's temporaries down to the first node that is not a transform
+    // (`anchor`) only, and takes the normal of that sub-tree by the plain n<i>() functions, which compute what they need
+    // themselves.  The temporaries below the anchor are then locals of the distance pass, dead at its end, not registers
+    // that live across the march loop.
+    // It pays where many temporaries sit below the anchor and normals are rare (chair.sce: six of them, 14.5 k normal
+    // passes a frame against 909 k trips; 69.3 -> 71.1 Grays/s), and costs a second evaluation of the sub-tree per normal:
+    // taken from kLeanFloats temporaries on (generate_scene_source tries the plain form first and counts them).
+    bool lean = false, below_anchor = false;
+    size_t anchor = 0;
+    int below_floats = 0;             // registers the temporaries below the anchor take
+    static constexpr int kLeanFloats = 6;
+    std::string locals;
+    std::string new_f() {
+        std::string v = "d" + std::to_string(counter++);
+        if (below_anchor && !in_norm) { ++below_floats; if (lean) { locals += "    float t" + v + ";\n"; return "t" + v; } }      // (d<i> and n<i> are the nodes' functions)
+        decl += "    float " + v + ";\n"; return "k." + v;
+    }
+    std::string new_p() {
+        std::string v = "p" + std::to_string(counter++);
+        if (below_anchor && !in_norm) { below_floats += 3; if (lean) { locals += "    P3 t" + v + ";\n"; return "t" + v; } }
+        decl += "    P3 " + v + ";\n"; return "k." + v;
+    }
     size_t kid(size_t i, int k) const { return i + static_cast<size_t>(nodes[i].o[k]); }
     static bool is_min(uint32_t t) { return t == RM_TYPE_KUNIGAJO_2 || t == RM_TYPE_KUNIGAJO_3 || t == RM_TYPE_KUNIGAJO_4; }
 
@@ -414,6 +434,7 @@ struct Fused {
         auto it = dmemo.find(key);
         if (it != dmemo.end() && usable(it->second)) return it->second.var;
         const rm_node& nd = nodes[i];
+        if (i == anchor && !in_norm) below_anchor = true;
         std::string v;
         auto leaf = [&](const std::string& call) { v = new_f(); dist += "    " + v + " = " + call + ";\n"; };
         switch (nd.type) {
@@ -586,6 +607,7 @@ struct Fused {
     void n(size_t i, const std::string& pv, const std::string& out, int depth) {
         const std::string pad(static_cast<size_t>(depth) * 4, ' ');
         const rm_node& nd = nodes[i];
+        if (lean && i == anchor) { norm += pad + out + " = " + fn('n', i) + "(" + pv + ");\n"; return; }
         switch (nd.type) {
         case RM_TYPE_SFERO:    norm += pad + out + " = " + pv + ";\n"; break;
         case RM_TYPE_KUBO:     norm += pad + out + " = kubo_norm(" + pv + ", " + lit3(nd.f) + ");\n"; break;
@@ -656,6 +678,13 @@ struct Fused {
 
     std::string source(size_t count, const unsigned char* seen) {
         weigh_lattices(count, seen);
+        anchor = 0;
+        for (;;) {
+            const uint32_t t = nodes[anchor].type;
+            if (t == RM_TYPE_MOVO || t == RM_TYPE_SENFINA_RIPETO || t == RM_TYPE_ROTACIOX || t == RM_TYPE_ROTACIOY ||
+                t == RM_TYPE_ROTACIOZ || t == RM_TYPE_ROTACIOQ) anchor = kid(anchor, 0);
+            else break;
+        }
         const std::string root = d(0, "E");
         in_norm = true;
         n(0, "E", "N", 1);
@@ -664,7 +693,7 @@ struct Fused {
         return "struct SceneKeep {\n" + decl + "};\n"
                "struct SceneCache {\n" + cache_decl + "};\n"
                "template <bool SKIP>\n"
-               "__device__ __forceinline__ float scene_dist_keep(P3 E, SceneKeep& k, SceneCache& s, unsigned long long amask) {\n" + dist +
+               "__device__ __forceinline__ float scene_dist_keep(P3 E, SceneKeep& k, SceneCache& s, unsigned long long amask) {\n" + locals + dist +
                "    (void)amask; (void)s;\n    return " + root + ";\n}\n"
                "__device__ __forceinline__ P3 scene_norm_keep(P3 E, const SceneKeep& k) {\n    P3 N{0.f, 0.f, 0.f};\n" + norm +
                "    (void)E; (void)k;\n    return N;\n}\n";
@@ -792,8 +821,16 @@ struct JitScene {
 
 )";
     } else {
-        Fused fused(nodes, exact);
-        s += fused.source(n, seen);
+        Fused plain(nodes, exact);
+        std::string body = plain.source(n, seen);
+        int want_lean = plain.below_floats >= Fused::kLeanFloats;
+        if (const char* env = std::getenv("RM_LEAN_KEEP")) want_lean = std::atoi(env);      // experiments only
+        if (want_lean) {
+            Fused fused(nodes, exact);
+            fused.lean = true;
+            body = fused.source(n, seen);
+        }
+        s += body;
         s += R"(
 struct JitScene {
     typedef SceneCache Scratch;
