@@ -188,6 +188,47 @@ def random_carved(seed):
     return solid
 
 
+def random_lattice(seed):
+    """A seeded scene that is mostly lattice: one to three nested senfina_ripeto (vectors along one axis, in a plane or
+    general, components of either sign, periods from 20 to 120) over a small solid, plain or as the komplemento of a
+    sphere larger than the cell (infinity.sce's shape).  For the generated code's cell_cache: rays that cross many cells,
+    run along cell boundaries and - from the far cameras of the test - start hundreds of cells out."""
+    rng = np.random.default_rng(seed)
+
+    def f(lo, hi):
+        return float(np.float32(rng.uniform(lo, hi)))
+
+    def vec(period):
+        k = rng.integers(0, 6)
+        sgn = -1.0 if rng.random() < 0.3 else 1.0
+        if k < 3:                                   # along one axis
+            v = [0.0, 0.0, 0.0]
+            v[k] = sgn * period
+            return tuple(v)
+        if k < 5:                                   # in a coordinate plane
+            v = [sgn * period, f(-0.4, 0.4) * period, 0.0]
+            rng.shuffle(v)
+            return tuple(float(x) for x in v)
+        return (sgn * period, f(-0.3, 0.3) * period, f(-0.3, 0.3) * period)
+
+    period = f(20, 120)
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        solid = ("komplemento", (), ("sfero", (0.65 * period,)))
+    elif kind == 1:
+        solid = ("sfero", (f(0.15, 0.35) * period,))
+    elif kind == 2:
+        solid = ("kubo", (f(0.1, 0.3) * period, f(0.1, 0.3) * period, f(0.1, 0.3) * period))
+    else:
+        solid = ("kunigajo_2", (), ("sfero", (0.2 * period,)), ("movo", (0.25 * period, 0.0, 0.1 * period), ("kubo", (0.1 * period,) * 3)))
+    t = solid
+    for _ in range(int(rng.integers(1, 4))):
+        t = ("senfina_ripeto", vec(period * f(0.8, 1.25)), t)
+    if rng.random() < 0.4:
+        t = ("movo", (f(-30, 30), 0.0, f(-30, 30)), t)
+    return t
+
+
 def tables():
     return {name: Tree(t).table() for name, t in SCENES.items()}
 

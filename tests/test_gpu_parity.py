@@ -228,6 +228,29 @@ def test_random_carved_solids(seed):
         assert_same_frame(rgba, hit, ref, "carved_%d_%s" % (seed, path))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RM_LATTICE_SEEDS", "16"))))
+def test_random_lattices(seed):
+    """Fuzz of the generated code's cell_cache (jit.cpp): scenes that are mostly senfina_ripeto (kat_scenes.random_lattice),
+    frames from a near and a far camera (cells beyond the 127 the cache keeps) on the three kernels, DIST and NORM at
+    seeded points near and far, against the oracle."""
+    table = scenes.Tree(kat_scenes.random_lattice(900 + seed)).table()
+    pts = np.concatenate([kat_scenes.points(64, seed=200 + seed, span=150.0),
+                          kat_scenes.points(32, seed=300 + seed, span=30000.0)])
+    want_d, want_n = O.dist_many(table, 0, pts), O.norm_many(table, 0, pts)
+    with api.Raymarching(64, 64) as rm:
+        rm.set_jit(2)
+        rm.set_nodes(table)
+        d_jit, n_jit = rm.eval_points(pts, 0, which=2, want_norm=True)
+    assert same_floats(d_jit, want_d) and same_floats(n_jit, want_n), "generated DIST / NORM differ from the oracle"
+    for far in (False, True):
+        info = O.default_info(1 + seed % 5, (seed * 7) % 19)
+        info["StartPos"] = (-9000.0 - 31 * seed, 40.0, 7000.0 + seed) if far else (-42.0 + seed % 5, 2.0 - seed % 3, 1.0 + seed % 4)
+        ref = O.render(table, 160, 96, info, threads=min(16, os.cpu_count() or 4))
+        for path in ("jit", "program"):
+            rgba, hit, _ = gpu_render(table, 160, 96, info, path)
+            assert_same_frame(rgba, hit, ref, "lattice_%d_%s_%s" % (seed, "far" if far else "near", path))
+
+
 def test_set_rays_kat():
     """kernel_SetRays (Source/cuda_kernels.cu:730-762) fused into the kernel."""
     for (w, h, phi) in [(640, 480, 0), (1920, 1080, 37), (7680, 4320, 119), (33, 17, 5)]:
