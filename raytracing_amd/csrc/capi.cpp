@@ -61,6 +61,10 @@ struct rm_ctx {
     uint32_t seq = 0;                 // launch sequence number
     uint32_t list_cap = 0, overflow_cap = 0;
     bool adaptive_grid = true;        // the grid follows the previous launch's work and longest tile (render_blocks)
+    // wavefronts per (work / longest tile).  Round 3, after the trips got cheaper: chair.sce 4K, one frame per launch, 0.313 ms
+    // at 1 (2048 wavefronts), 0.248-0.250 at 1.5-2.5 (4096-5120), 0.293 at 3; csg1024 4K 5.2 -> 4.8 ms at 2; the other
+    // scenes and sizes within a few per cent either way (RM_GRID_FACTOR, read by rm_create)
+    double grid_factor = 2.0;
     size_t tiles_per_wave = 8;        // grid: at least this many tiles per wavefront (RM_TILES_PER_WAVE, read by rm_create)
     size_t blocks_per_cu_forced = 0;  // experiments (RM_BLOCKS_PER_CU, read by rm_create): 0 = what the kernel's occupancy allows
     bool feedback = true;             // launches file their tiles by cost for the next launch
@@ -224,7 +228,7 @@ hipError_t reset_schedule(rm_ctx* c) {
 // or infinity.sce, has work for every wavefront the chip holds).  Both figures are the previous launch's.
 size_t wanted_waves(const rm_ctx* c, size_t tiles) {
     if (c->trips_per_tile <= 0 || c->longest_tile == 0) return ~size_t(0);
-    return static_cast<size_t>(c->trips_per_tile * static_cast<double>(tiles) / c->longest_tile) + 1;
+    return static_cast<size_t>(c->grid_factor * c->trips_per_tile * static_cast<double>(tiles) / c->longest_tile) + 1;
 }
 
 unsigned render_blocks(const rm_ctx* c, bool jit, size_t frames) {
@@ -240,7 +244,10 @@ unsigned render_blocks(const rm_ctx* c, bool jit, size_t frames) {
     size_t resident = static_cast<size_t>(c->cus) * per_cu;
     if (!c->blocks_per_cu_forced && c->adaptive_grid) {
         const size_t waves = wanted_waves(c, tiles);                     // ~0 when nothing has been measured yet
-        const size_t by_work = waves > 4 * resident ? resident : (waves + 3) / 4;
+        size_t by_work = waves > 4 * resident ? resident : (waves + 3) / 4;
+        // the same number of workgroups on every CU: a wavefront is the slower the more share its SIMD, and the long
+        // tiles should all run at one speed
+        by_work = (by_work + c->cus - 1) / c->cus * c->cus;
         const size_t floor = static_cast<size_t>(c->cus) * 2;            // never below two workgroups per CU
         if (by_work < resident) resident = by_work > floor ? by_work : floor;
     }
@@ -478,6 +485,7 @@ int rm_create(int device, size_t width, size_t height, rm_ctx** out) {
     c->device = device; c->width = width; c->height = height;
     // experiment knobs, read here once: nothing on the launch path looks at the environment
     if (const char* env = std::getenv("RM_ADAPTIVE_GRID")) c->adaptive_grid = std::atoi(env) != 0;
+    if (const char* env = std::getenv("RM_GRID_FACTOR")) if (std::atof(env) > 0) c->grid_factor = std::atof(env);
     if (const char* env = std::getenv("RM_TILES_PER_WAVE")) if (std::atoi(env) > 0) c->tiles_per_wave = static_cast<size_t>(std::atoi(env));
     if (const char* env = std::getenv("RM_BLOCKS_PER_CU")) if (std::atoi(env) > 0) c->blocks_per_cu_forced = static_cast<size_t>(std::atoi(env));
     if (const char* env = std::getenv("RM_RAY_WINDOWS")) c->ray_windows = std::atoi(env) != 0;          // experiments only
